@@ -1,0 +1,148 @@
+/* batchsim.h — C-ABI of libbatchsim.so: the MI355X-native batched physics step.
+ *
+ * This is the drop-in boundary of SURVEY.md §8b.  The reference reaches its physics step
+ * through mujoco-py's Cython binding of libmujoco210.so; its only call sites are
+ *   reference src/Mujoco_XML.py:4    from mujoco_py import load_model_from_xml, MjSim, MjViewer
+ *   reference src/Mujoco_XML.py:341  model = load_model_from_xml(model_str)
+ *   reference src/Mujoco_XML.py:342  sim = MjSim(model)
+ * and BASELINE.json's north_star names the rest of the surface (sim.step(),
+ * sim.data.qpos/qvel/ctrl).  Each entry point below cites the mujoco-py / MuJoCo call it
+ * replaces.  Plain pointers and sizes only; no torch types.  Every function returns 0 or a
+ * negative bs_status; bs_last_error() gives the message (thread-local).
+ *
+ * Device layout: every per-environment field is a row-major [rows][E_pad] array of its
+ * element type (env-minor, so a wavefront's 64 lanes read 512 contiguous bytes); E_pad is
+ * n_envs rounded up to 64.  bs_get_ptr reports (rows, n_envs) with strides (E_pad, 1).
+ *
+ * Threading: one bs_sim = one device + one HIP stream; calls on a handle must be serialised
+ * by the caller; bs_step / bs_forward are asynchronous until bs_sync or a host copy.
+ */
+#ifndef BATCHSIM_H
+#define BATCHSIM_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BS_VERSION 100
+
+typedef enum bs_status {
+  BS_OK = 0,
+  BS_ERR_INVALID = -1,     /* bad argument / inconsistent model description */
+  BS_ERR_NODEVICE = -2,    /* no usable HIP device: there is NO CPU fallback */
+  BS_ERR_HIP = -3,         /* a HIP runtime call failed */
+  BS_ERR_UNSUPPORTED = -4, /* feature outside the implemented subset */
+  BS_ERR_NOMEM = -5
+} bs_status;
+
+/* Flattened model (the build's mjModel): arrays produced by the host-side MJCF compiler
+ * (mujoco_amd/mjcf.py), copied to the device once by bs_model_create.  Field names follow
+ * mjModel.  Replaces the result of mujoco-py load_model_from_xml (reference
+ * src/Mujoco_XML.py:341). */
+typedef struct bs_model_desc {
+  int32_t nbody, njnt, nv, nu, ngeom, neq, nmesh, nM, npair, nhullvert, nhulladj;
+  int32_t integrator; /* 0 Euler, 1 RK4 */
+  int32_t solver;     /* 0 PGS, 1 CG, 2 Newton */
+  int32_t iterations, ls_iterations, disableflags, mpr_iterations;
+  double timestep, gravity[3], tolerance, ls_tolerance, impratio, mpr_tolerance, meaninertia;
+  const int32_t *body_parentid, *body_rootid, *body_weldid, *body_jntadr, *body_jntnum,
+      *body_dofadr, *body_dofnum;
+  const double *body_pos, *body_quat, *body_ipos, *body_iquat, *body_mass, *body_subtreemass,
+      *body_inertia, *body_invweight0;
+  const int32_t *jnt_type, *jnt_bodyid, *jnt_qposadr, *jnt_dofadr, *jnt_limited;
+  const double *jnt_pos, *jnt_axis, *jnt_range, *jnt_margin, *jnt_stiffness, *jnt_solref,
+      *jnt_solimp, *qpos0, *qpos_spring;
+  const int32_t *dof_bodyid, *dof_jntid, *dof_parentid, *dof_Madr;
+  const double *dof_armature, *dof_damping, *dof_frictionloss, *dof_solref, *dof_solimp,
+      *dof_invweight0;
+  const int32_t *geom_type, *geom_bodyid, *geom_dataid, *geom_condim, *geom_priority;
+  const double *geom_pos, *geom_quat, *geom_size, *geom_friction, *geom_margin, *geom_gap,
+      *geom_solref, *geom_solimp, *geom_solmix, *geom_rbound;
+  const int32_t *mesh_vertadr, *mesh_vertnum, *hull_adj_start, *hull_adj;
+  const double *hull_vert;
+  const int32_t *actuator_trnid, *actuator_ctrllimited, *actuator_forcelimited;
+  const double *actuator_ctrlrange, *actuator_forcerange, *actuator_gear, *actuator_gainprm,
+      *actuator_biasprm;
+  const int32_t *pair_geom1, *pair_geom2;
+  const int32_t *eq_obj1id, *eq_obj2id, *eq_active;
+  const double *eq_data, *eq_solref, *eq_solimp;
+} bs_model_desc;
+
+typedef struct bs_options {
+  int32_t max_contacts_per_env; /* cap for the compacted contact list (0 = default 32) */
+  int32_t nsubsteps_hint;       /* informational */
+  int32_t reserved[6];
+} bs_options;
+
+typedef struct bs_model bs_model;
+typedef struct bs_sim bs_sim;
+
+/* Field ids for bs_get_ptr / bs_copy_field: the mjData members mujoco-py exposes as
+ * sim.data.<name> (BASELINE.json north_star: qpos/qvel/ctrl). */
+typedef enum bs_field {
+  BS_F_QPOS = 0, BS_F_QVEL, BS_F_CTRL, BS_F_QFRC_APPLIED, BS_F_QACC, BS_F_QACC_WARMSTART,
+  BS_F_TIME,
+  BS_F_XPOS, BS_F_XQUAT, BS_F_XIPOS, BS_F_XANCHOR, BS_F_XAXIS, BS_F_ROOTCOM,
+  BS_F_CINERT, BS_F_CRB, BS_F_CDOF, BS_F_QM, BS_F_QLD, BS_F_QLDIAGINV,
+  BS_F_CVEL, BS_F_QFRC_BIAS, BS_F_QFRC_PASSIVE, BS_F_ACTUATOR_FORCE, BS_F_QFRC_ACTUATOR,
+  BS_F_QFRC_SMOOTH, BS_F_QACC_SMOOTH, BS_F_QFRC_CONSTRAINT,
+  BS_F_EFC_D, BS_F_EFC_AREF, BS_F_EFC_FORCE,
+  BS_F_SOLVER_ITER, /* int32 [1][E] */
+  BS_F_WARNING,     /* int32 [1][E]: bit0 bad qpos, bit1 bad qvel, bit2 bad qacc, bit3 contact overflow */
+  BS_F_NEFC,        /* int32 [1][E]: active constraint rows */
+  BS_F_XMAT,        /* derived on demand from xquat */
+  BS_F_GEOM_XPOS, BS_F_GEOM_XMAT,
+  BS_F_COUNT
+} bs_field;
+
+/* mujoco-py has no counterpart (library metadata). */
+int bs_version(void);
+const char *bs_last_error(void);
+int bs_device_count(int *n);
+
+/* Replaces mujoco_py.load_model_from_xml's native half: mj_loadXML's result as device arrays
+ * (reference src/Mujoco_XML.py:341).  Host arrays may be released after the call. */
+int bs_model_create(const bs_model_desc *desc, bs_model **out);
+int bs_model_destroy(bs_model *m);
+
+/* Replaces mujoco_py.MjSim(model) = mj_makeData + mj_resetData (reference
+ * src/Mujoco_XML.py:342), for n_envs lockstep environments on HIP device `device`.
+ * env_model_id (nullable) selects a model per environment and must be non-decreasing. */
+int bs_sim_create(const bs_model *const *models, int n_models, const int32_t *env_model_id,
+                  int64_t n_envs, int device, const bs_options *opt, bs_sim **out);
+int bs_sim_destroy(bs_sim *s);
+
+/* Run on a caller-owned hipStream_t (e.g. PyTorch's current stream; 0 is the legacy null
+ * stream) instead of the sim's own; use_own_stream != 0 switches back to the sim's stream. */
+int bs_set_stream(bs_sim *s, void *hip_stream, int use_own_stream);
+
+/* Replaces MjSim.step() = mj_step, n_steps times (mujoco-py's nsubsteps), all envs in lockstep. */
+int bs_step(bs_sim *s, int n_steps);
+/* Replaces MjSim.forward() = mj_forward. */
+int bs_forward(bs_sim *s);
+/* Replaces MjSim.reset() = mj_resetData; env_mask (host, n_envs bytes, nullable = all). */
+int bs_reset(bs_sim *s, const uint8_t *env_mask);
+
+/* Zero-copy device view of a field (what sim.data.<field> wraps). shape/stride in elements. */
+int bs_get_ptr(bs_sim *s, int field_id, void **dev_ptr, int64_t shape[2], int64_t stride[2],
+               int *is_int32);
+/* direction 0: device -> host (dense [rows][n_envs]); 1: host -> device. Synchronises. */
+int bs_copy_field(bs_sim *s, int field_id, void *host, int direction);
+
+/* sim.data.ncon / sim.data.contact[i].geom1, geom2, dist for one environment. */
+int bs_get_contacts(bs_sim *s, int64_t env, int32_t *geom1, int32_t *geom2, double *dist, int cap,
+                    int *n);
+
+int bs_sync(bs_sim *s);
+/* Runs one step stage by stage with HIP events between the stages and returns the elapsed
+ * ms per stage: [0] position (A1-A4) [1] collision (A5-A6) [2] velocity+actuation+accel (A8-A10)
+ * [3] constraints (A7+A11) [4] integrate (A12/A13).  Advances the state by one step. */
+int bs_stage_times(bs_sim *s, double *ms, int n);
+/* Times n_steps of bs_step with HIP events on the sim's stream; returns elapsed ms. */
+int bs_timed_steps(bs_sim *s, int n_steps, double *elapsed_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

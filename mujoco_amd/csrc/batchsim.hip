@@ -1,0 +1,658 @@
+// batchsim.hip — host side of libbatchsim.so: the C-ABI of include/batchsim.h over the
+// gfx950 kernels in physics_dev.h.  There is no CPU fallback: without a HIP device every
+// entry point that needs one fails with BS_ERR_NODEVICE.
+#include "../../include/batchsim.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "physics_dev.h"
+
+// ------------------------------------------------------------------ errors
+static thread_local std::string g_err;
+static int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+#define HIPCHK(call)                                                                         \
+  do {                                                                                       \
+    hipError_t e_ = (call);                                                                  \
+    if (e_ != hipSuccess)                                                                    \
+      return fail(BS_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, \
+                  __LINE__);                                                                 \
+  } while (0)
+
+extern "C" int bs_version(void) { return BS_VERSION; }
+extern "C" const char* bs_last_error(void) { return g_err.c_str(); }
+extern "C" int bs_device_count(int* n) {
+  if (!n) return fail(BS_ERR_INVALID, "bs_device_count: null argument");
+  int c = 0;
+  hipError_t e = hipGetDeviceCount(&c);
+  if (e != hipSuccess) { (void)hipGetLastError(); c = 0; }
+  *n = c;
+  return BS_OK;
+}
+
+// ------------------------------------------------------------------ model
+// Host copy of everything (validated), uploaded lazily per device.
+struct HostModel {
+  bs_model_desc s;  // scalars only are meaningful; pointers are replaced by the vectors below
+  std::vector<std::vector<int32_t>> iv;
+  std::vector<std::vector<double>> dv;
+};
+
+struct DeviceImage {
+  int device = -1;
+  void* blob = nullptr;
+  DevModel dm;
+};
+
+struct bs_model {
+  bs_model_desc d;  // pointers point into the vectors below
+  std::vector<int32_t> ibuf;
+  std::vector<double> dbuf;
+  // derived fixed constraint-row layout
+  std::vector<int32_t> eq_dof1, eq_dof2, eq_jnt1, eq_jnt2, eq_Hadr, fric_dof, lim_jnt;
+  std::vector<double> eq_data, eq_solref, eq_solimp;
+  int damped = 0, hess_sparse = 1;
+  std::vector<DeviceImage> images;
+};
+
+namespace {
+struct Packer {
+  std::vector<char> bytes;
+  size_t add(const void* p, size_t n) {
+    size_t off = (bytes.size() + 15) & ~size_t(15);
+    bytes.resize(off + (n ? n : 16));
+    if (n) memcpy(bytes.data() + off, p, n);
+    return off;
+  }
+};
+}  // namespace
+
+#define CHECK_PTR(field, count)                                                        \
+  if ((count) > 0 && !desc->field) return fail(BS_ERR_INVALID, "bs_model_create: %s is null", #field)
+
+extern "C" int bs_model_create(const bs_model_desc* desc, bs_model** out) {
+  if (!desc || !out) return fail(BS_ERR_INVALID, "bs_model_create: null argument");
+  const int nb = desc->nbody, nj = desc->njnt, nv = desc->nv, nu = desc->nu, ng = desc->ngeom,
+            ne = desc->neq;
+  if (nb < 1 || nj < 0 || nv != nj || nu < 0 || ng < 0 || ne < 0 || desc->nM < nv)
+    return fail(BS_ERR_INVALID, "bs_model_create: inconsistent sizes (nbody=%d njnt=%d nv=%d nM=%d)", nb,
+                nj, nv, desc->nM);
+  if (!(desc->timestep > 0)) return fail(BS_ERR_INVALID, "bs_model_create: timestep must be > 0");
+  if (desc->solver != 2)
+    return fail(BS_ERR_UNSUPPORTED, "bs_model_create: only the Newton solver (2) is implemented, got %d",
+                desc->solver);
+  if (desc->integrator != 0 && desc->integrator != 1)
+    return fail(BS_ERR_INVALID, "bs_model_create: integrator must be 0 (Euler) or 1 (RK4)");
+  CHECK_PTR(body_parentid, nb); CHECK_PTR(body_rootid, nb); CHECK_PTR(body_jntadr, nb);
+  CHECK_PTR(body_jntnum, nb); CHECK_PTR(body_dofadr, nb); CHECK_PTR(body_dofnum, nb);
+  CHECK_PTR(body_pos, nb); CHECK_PTR(body_quat, nb); CHECK_PTR(body_ipos, nb); CHECK_PTR(body_iquat, nb);
+  CHECK_PTR(body_mass, nb); CHECK_PTR(body_subtreemass, nb); CHECK_PTR(body_inertia, nb);
+  CHECK_PTR(body_invweight0, nb);
+  CHECK_PTR(jnt_type, nj); CHECK_PTR(jnt_bodyid, nj); CHECK_PTR(jnt_qposadr, nj); CHECK_PTR(jnt_dofadr, nj);
+  CHECK_PTR(jnt_limited, nj); CHECK_PTR(jnt_pos, nj); CHECK_PTR(jnt_axis, nj); CHECK_PTR(jnt_range, nj);
+  CHECK_PTR(jnt_margin, nj); CHECK_PTR(jnt_stiffness, nj); CHECK_PTR(jnt_solref, nj);
+  CHECK_PTR(jnt_solimp, nj); CHECK_PTR(qpos0, nj); CHECK_PTR(qpos_spring, nj);
+  CHECK_PTR(dof_bodyid, nv); CHECK_PTR(dof_jntid, nv); CHECK_PTR(dof_parentid, nv); CHECK_PTR(dof_Madr, nv);
+  CHECK_PTR(dof_armature, nv); CHECK_PTR(dof_damping, nv); CHECK_PTR(dof_frictionloss, nv);
+  CHECK_PTR(dof_solref, nv); CHECK_PTR(dof_solimp, nv); CHECK_PTR(dof_invweight0, nv);
+  CHECK_PTR(geom_bodyid, ng); CHECK_PTR(geom_pos, ng); CHECK_PTR(geom_quat, ng);
+  CHECK_PTR(actuator_trnid, nu); CHECK_PTR(actuator_ctrllimited, nu); CHECK_PTR(actuator_forcelimited, nu);
+  CHECK_PTR(actuator_ctrlrange, nu); CHECK_PTR(actuator_forcerange, nu); CHECK_PTR(actuator_gear, nu);
+  CHECK_PTR(actuator_gainprm, nu); CHECK_PTR(actuator_biasprm, nu);
+  CHECK_PTR(eq_obj1id, ne); CHECK_PTR(eq_obj2id, ne); CHECK_PTR(eq_active, ne); CHECK_PTR(eq_data, ne);
+  CHECK_PTR(eq_solref, ne); CHECK_PTR(eq_solimp, ne);
+
+  // structural validation: the kernels index with these, so reject anything out of range
+  for (int b = 0; b < nb; b++) {
+    if (b > 0 && (desc->body_parentid[b] < 0 || desc->body_parentid[b] >= b))
+      return fail(BS_ERR_INVALID, "body %d: parent id %d must precede it", b, desc->body_parentid[b]);
+    if (desc->body_rootid[b] < 0 || desc->body_rootid[b] > b)
+      return fail(BS_ERR_INVALID, "body %d: bad root id", b);
+    if (desc->body_jntnum[b] < 0 || (desc->body_jntnum[b] > 0 &&
+        (desc->body_jntadr[b] < 0 || desc->body_jntadr[b] + desc->body_jntnum[b] > nj)))
+      return fail(BS_ERR_INVALID, "body %d: bad joint range", b);
+    if (desc->body_dofnum[b] != desc->body_jntnum[b] ||
+        (desc->body_dofnum[b] > 0 && desc->body_dofadr[b] != desc->body_jntadr[b]))
+      return fail(BS_ERR_INVALID, "body %d: dof range must equal joint range (hinge/slide only)", b);
+  }
+  int nM = 0;
+  for (int i = 0; i < nv; i++) {
+    if (desc->jnt_type[i] != BS_JNT_HINGE && desc->jnt_type[i] != BS_JNT_SLIDE)
+      return fail(BS_ERR_UNSUPPORTED, "joint %d: only hinge and slide joints are supported", i);
+    if (desc->jnt_qposadr[i] != i || desc->jnt_dofadr[i] != i || desc->dof_jntid[i] != i)
+      return fail(BS_ERR_INVALID, "joint %d: qpos/dof address must equal the joint id", i);
+    if (desc->dof_parentid[i] >= i || desc->dof_parentid[i] < -1)
+      return fail(BS_ERR_INVALID, "dof %d: bad parent", i);
+    if (desc->jnt_bodyid[i] < 1 || desc->jnt_bodyid[i] >= nb || desc->dof_bodyid[i] != desc->jnt_bodyid[i])
+      return fail(BS_ERR_INVALID, "joint %d: bad body id", i);
+    if (desc->dof_Madr[i] != nM) return fail(BS_ERR_INVALID, "dof %d: bad dof_Madr", i);
+    for (int k = i; k >= 0; k = desc->dof_parentid[k]) nM++;
+  }
+  if (nM != desc->nM) return fail(BS_ERR_INVALID, "nM=%d does not match the dof tree (%d)", desc->nM, nM);
+  for (int u = 0; u < nu; u++)
+    if (desc->actuator_trnid[u] < 0 || desc->actuator_trnid[u] >= nj)
+      return fail(BS_ERR_INVALID, "actuator %d: bad joint id", u);
+  for (int g = 0; g < ng; g++)
+    if (desc->geom_bodyid[g] < 0 || desc->geom_bodyid[g] >= nb)
+      return fail(BS_ERR_INVALID, "geom %d: bad body id", g);
+
+  bs_model* m = new bs_model();
+  m->d = *desc;
+  // deep copy of the arrays the device image needs (sizes in elements)
+  struct IA { const int32_t** p; size_t n; };
+  struct DA { const double** p; size_t n; };
+  IA ia[] = {{&m->d.body_parentid, (size_t)nb}, {&m->d.body_rootid, (size_t)nb}, {&m->d.body_jntadr, (size_t)nb},
+             {&m->d.body_jntnum, (size_t)nb}, {&m->d.body_dofadr, (size_t)nb}, {&m->d.body_dofnum, (size_t)nb},
+             {&m->d.jnt_type, (size_t)nj}, {&m->d.jnt_bodyid, (size_t)nj}, {&m->d.jnt_qposadr, (size_t)nj},
+             {&m->d.jnt_dofadr, (size_t)nj}, {&m->d.jnt_limited, (size_t)nj}, {&m->d.dof_bodyid, (size_t)nv},
+             {&m->d.dof_jntid, (size_t)nv}, {&m->d.dof_parentid, (size_t)nv}, {&m->d.dof_Madr, (size_t)nv},
+             {&m->d.geom_bodyid, (size_t)ng}, {&m->d.actuator_trnid, (size_t)nu},
+             {&m->d.actuator_ctrllimited, (size_t)nu}, {&m->d.actuator_forcelimited, (size_t)nu},
+             {&m->d.eq_obj1id, (size_t)ne}, {&m->d.eq_obj2id, (size_t)ne}, {&m->d.eq_active, (size_t)ne}};
+  DA da[] = {{&m->d.body_pos, (size_t)nb * 3}, {&m->d.body_quat, (size_t)nb * 4}, {&m->d.body_ipos, (size_t)nb * 3},
+             {&m->d.body_iquat, (size_t)nb * 4}, {&m->d.body_mass, (size_t)nb}, {&m->d.body_subtreemass, (size_t)nb},
+             {&m->d.body_inertia, (size_t)nb * 3}, {&m->d.body_invweight0, (size_t)nb * 2},
+             {&m->d.jnt_pos, (size_t)nj * 3}, {&m->d.jnt_axis, (size_t)nj * 3}, {&m->d.jnt_range, (size_t)nj * 2},
+             {&m->d.jnt_margin, (size_t)nj}, {&m->d.jnt_stiffness, (size_t)nj}, {&m->d.jnt_solref, (size_t)nj * 2},
+             {&m->d.jnt_solimp, (size_t)nj * 5}, {&m->d.qpos0, (size_t)nj}, {&m->d.qpos_spring, (size_t)nj},
+             {&m->d.dof_armature, (size_t)nv}, {&m->d.dof_damping, (size_t)nv}, {&m->d.dof_frictionloss, (size_t)nv},
+             {&m->d.dof_solref, (size_t)nv * 2}, {&m->d.dof_solimp, (size_t)nv * 5}, {&m->d.dof_invweight0, (size_t)nv},
+             {&m->d.geom_pos, (size_t)ng * 3}, {&m->d.geom_quat, (size_t)ng * 4},
+             {&m->d.actuator_ctrlrange, (size_t)nu * 2}, {&m->d.actuator_forcerange, (size_t)nu * 2},
+             {&m->d.actuator_gear, (size_t)nu}, {&m->d.actuator_gainprm, (size_t)nu * 3},
+             {&m->d.actuator_biasprm, (size_t)nu * 3}, {&m->d.eq_data, (size_t)ne * 5},
+             {&m->d.eq_solref, (size_t)ne * 2}, {&m->d.eq_solimp, (size_t)ne * 5}};
+  size_t ni = 0, nd = 0;
+  for (auto& a : ia) ni += a.n;
+  for (auto& a : da) nd += a.n;
+  m->ibuf.resize(ni + 1);
+  m->dbuf.resize(nd + 1);
+  size_t oi = 0, od = 0;
+  for (auto& a : ia) {
+    if (a.n) memcpy(m->ibuf.data() + oi, *a.p, a.n * sizeof(int32_t));
+    *a.p = m->ibuf.data() + oi;
+    oi += a.n;
+  }
+  for (auto& a : da) {
+    if (a.n) memcpy(m->dbuf.data() + od, *a.p, a.n * sizeof(double));
+    *a.p = m->dbuf.data() + od;
+    od += a.n;
+  }
+
+  // fixed constraint-row layout
+  const int flags = desc->disableflags;
+  if (!(flags & BS_DSBL_EQUALITY))
+    for (int e = 0; e < ne; e++) {
+      if (!m->d.eq_active[e]) continue;
+      const int j1 = m->d.eq_obj1id[e], j2 = m->d.eq_obj2id[e];
+      if (j1 < 0 || j1 >= nj || j2 >= nj) {
+        delete m;
+        return fail(BS_ERR_INVALID, "equality %d: bad joint id", e);
+      }
+      m->eq_jnt1.push_back(j1); m->eq_jnt2.push_back(j2);
+      const int d1 = j1, d2 = j2 >= 0 ? j2 : -1;
+      m->eq_dof1.push_back(d1); m->eq_dof2.push_back(d2);
+      int hadr = -1;
+      if (d2 >= 0 && d1 != d2) {
+        const int hi = d1 > d2 ? d1 : d2, lo = d1 > d2 ? d2 : d1;
+        int adr = m->d.dof_Madr[hi];
+        for (int k = hi; k >= 0; k = m->d.dof_parentid[k], adr++)
+          if (k == lo) { hadr = adr; break; }
+        if (hadr < 0) m->hess_sparse = 0;
+      } else if (d2 >= 0) {
+        delete m;
+        return fail(BS_ERR_INVALID, "equality %d couples a joint with itself", e);
+      }
+      m->eq_Hadr.push_back(hadr);
+      for (int k = 0; k < 5; k++) m->eq_data.push_back(m->d.eq_data[5 * e + k]);
+      for (int k = 0; k < 2; k++) m->eq_solref.push_back(m->d.eq_solref[2 * e + k]);
+      for (int k = 0; k < 5; k++) m->eq_solimp.push_back(m->d.eq_solimp[5 * e + k]);
+    }
+  if (!m->hess_sparse) {
+    delete m;
+    return fail(BS_ERR_UNSUPPORTED,
+                "a joint equality couples dofs on different branches of the tree; the dense-Hessian "
+                "solver path is not implemented yet");
+  }
+  if (!(flags & BS_DSBL_FRICTIONLOSS))
+    for (int i = 0; i < nv; i++)
+      if (m->d.dof_frictionloss[i] > 0) m->fric_dof.push_back(i);
+  if (!(flags & BS_DSBL_LIMIT))
+    for (int j = 0; j < nj; j++)
+      if (m->d.jnt_limited[j]) m->lim_jnt.push_back(j);
+  for (int i = 0; i < nv; i++) m->damped |= m->d.dof_damping[i] > 0;
+  *out = m;
+  return BS_OK;
+}
+
+static void free_images(bs_model* m) {
+  for (auto& im : m->images)
+    if (im.blob) {
+      (void)hipSetDevice(im.device);
+      (void)hipFree(im.blob);
+    }
+  m->images.clear();
+}
+
+extern "C" int bs_model_destroy(bs_model* m) {
+  if (!m) return BS_OK;
+  free_images(m);
+  delete m;
+  return BS_OK;
+}
+
+// upload (once per device) and return the device-side view
+static int model_image(bs_model* m, int device, const DevModel** out) {
+  for (auto& im : m->images)
+    if (im.device == device) { *out = &im.dm; return BS_OK; }
+  Packer pk;
+  const bs_model_desc& s = m->d;
+  const int nb = s.nbody, nj = s.njnt, nv = s.nv, nu = s.nu, ng = s.ngeom;
+  DevModel dm;
+  memset(&dm, 0, sizeof dm);
+  dm.nbody = nb; dm.njnt = nj; dm.nv = nv; dm.nu = nu; dm.ngeom = ng; dm.nM = s.nM; dm.npair = s.npair;
+  dm.neq = (int)m->eq_dof1.size(); dm.nfric = (int)m->fric_dof.size(); dm.nlim = (int)m->lim_jnt.size();
+  dm.nrow = dm.neq + dm.nfric + 2 * dm.nlim;
+  dm.integrator = s.integrator; dm.iterations = s.iterations; dm.ls_iterations = s.ls_iterations;
+  dm.disableflags = s.disableflags; dm.damped = m->damped; dm.hess_sparse = m->hess_sparse;
+  dm.timestep = s.timestep; memcpy(dm.gravity, s.gravity, sizeof dm.gravity);
+  dm.tolerance = s.tolerance; dm.ls_tolerance = s.ls_tolerance; dm.impratio = s.impratio;
+  dm.meaninertia = s.meaninertia;
+  struct Fix { size_t off; void** slot; };
+  std::vector<Fix> fix;
+#define PUT_I(dst, src, n) fix.push_back({pk.add(src, (size_t)(n) * sizeof(int32_t)), (void**)&dm.dst})
+#define PUT_D(dst, src, n) fix.push_back({pk.add(src, (size_t)(n) * sizeof(double)), (void**)&dm.dst})
+  PUT_I(body_parentid, s.body_parentid, nb); PUT_I(body_rootid, s.body_rootid, nb);
+  PUT_I(body_jntadr, s.body_jntadr, nb); PUT_I(body_jntnum, s.body_jntnum, nb);
+  PUT_I(body_dofadr, s.body_dofadr, nb); PUT_I(body_dofnum, s.body_dofnum, nb);
+  PUT_D(body_pos, s.body_pos, nb * 3); PUT_D(body_quat, s.body_quat, nb * 4);
+  PUT_D(body_ipos, s.body_ipos, nb * 3); PUT_D(body_iquat, s.body_iquat, nb * 4);
+  PUT_D(body_mass, s.body_mass, nb); PUT_D(body_subtreemass, s.body_subtreemass, nb);
+  PUT_D(body_inertia, s.body_inertia, nb * 3); PUT_D(body_invweight0, s.body_invweight0, nb * 2);
+  PUT_I(jnt_type, s.jnt_type, nj); PUT_I(jnt_bodyid, s.jnt_bodyid, nj); PUT_I(jnt_qposadr, s.jnt_qposadr, nj);
+  PUT_I(jnt_dofadr, s.jnt_dofadr, nj); PUT_I(jnt_limited, s.jnt_limited, nj);
+  PUT_D(jnt_pos, s.jnt_pos, nj * 3); PUT_D(jnt_axis, s.jnt_axis, nj * 3); PUT_D(jnt_range, s.jnt_range, nj * 2);
+  PUT_D(jnt_margin, s.jnt_margin, nj); PUT_D(jnt_stiffness, s.jnt_stiffness, nj);
+  PUT_D(jnt_solref, s.jnt_solref, nj * 2); PUT_D(jnt_solimp, s.jnt_solimp, nj * 5);
+  PUT_D(qpos0, s.qpos0, nj); PUT_D(qpos_spring, s.qpos_spring, nj);
+  PUT_I(dof_bodyid, s.dof_bodyid, nv); PUT_I(dof_jntid, s.dof_jntid, nv);
+  PUT_I(dof_parentid, s.dof_parentid, nv); PUT_I(dof_Madr, s.dof_Madr, nv);
+  PUT_D(dof_armature, s.dof_armature, nv); PUT_D(dof_damping, s.dof_damping, nv);
+  PUT_D(dof_frictionloss, s.dof_frictionloss, nv); PUT_D(dof_solref, s.dof_solref, nv * 2);
+  PUT_D(dof_solimp, s.dof_solimp, nv * 5); PUT_D(dof_invweight0, s.dof_invweight0, nv);
+  PUT_I(geom_bodyid, s.geom_bodyid, ng); PUT_D(geom_pos, s.geom_pos, ng * 3); PUT_D(geom_quat, s.geom_quat, ng * 4);
+  PUT_I(actuator_trnid, s.actuator_trnid, nu); PUT_I(actuator_ctrllimited, s.actuator_ctrllimited, nu);
+  PUT_I(actuator_forcelimited, s.actuator_forcelimited, nu);
+  PUT_D(actuator_ctrlrange, s.actuator_ctrlrange, nu * 2); PUT_D(actuator_forcerange, s.actuator_forcerange, nu * 2);
+  PUT_D(actuator_gear, s.actuator_gear, nu); PUT_D(actuator_gainprm, s.actuator_gainprm, nu * 3);
+  PUT_D(actuator_biasprm, s.actuator_biasprm, nu * 3);
+  PUT_I(eq_dof1, m->eq_dof1.data(), dm.neq); PUT_I(eq_dof2, m->eq_dof2.data(), dm.neq);
+  PUT_I(eq_jnt1, m->eq_jnt1.data(), dm.neq); PUT_I(eq_jnt2, m->eq_jnt2.data(), dm.neq);
+  PUT_I(eq_Hadr, m->eq_Hadr.data(), dm.neq);
+  PUT_D(eq_data, m->eq_data.data(), dm.neq * 5); PUT_D(eq_solref, m->eq_solref.data(), dm.neq * 2);
+  PUT_D(eq_solimp, m->eq_solimp.data(), dm.neq * 5);
+  PUT_I(fric_dof, m->fric_dof.data(), dm.nfric); PUT_I(lim_jnt, m->lim_jnt.data(), dm.nlim);
+#undef PUT_I
+#undef PUT_D
+  HIPCHK(hipSetDevice(device));
+  void* blob = nullptr;
+  HIPCHK(hipMalloc(&blob, pk.bytes.size()));
+  HIPCHK(hipMemcpy(blob, pk.bytes.data(), pk.bytes.size(), hipMemcpyHostToDevice));
+  for (auto& f : fix) *f.slot = (char*)blob + f.off;
+  DeviceImage im;
+  im.device = device; im.blob = blob; im.dm = dm;
+  m->images.push_back(im);
+  *out = &m->images.back().dm;
+  return BS_OK;
+}
+
+// ------------------------------------------------------------------ sim
+struct FieldInfo {
+  void* ptr = nullptr;
+  int rows = 0;
+  bool is_int = false;
+};
+
+struct bs_sim {
+  bs_model* model = nullptr;
+  DevModel dm;
+  DevData dd;
+  int device = 0;
+  long n_envs = 0, E = 0;
+  hipStream_t own_stream = nullptr, stream = nullptr;
+  void* arena = nullptr;
+  size_t arena_bytes = 0;
+  FieldInfo fields[BS_F_COUNT];
+  double* derived = nullptr;  // scratch for on-demand fields (xmat, geom_xpos, geom_xmat)
+  size_t derived_rows = 0;
+  hipEvent_t ev[8];
+  bool events = false;
+};
+
+// kernels ----------------------------------------------------------------------------------
+#define BS_BLOCK 64
+
+__global__ __launch_bounds__(BS_BLOCK) void k_step(DevModel m, DevData d, int nsteps) {
+  const long e = (long)blockIdx.x * BS_BLOCK + threadIdx.x;
+  if (e >= d.n_envs) return;
+  for (int s = 0; s < nsteps; s++) env_step(m, d, e);
+}
+__global__ __launch_bounds__(BS_BLOCK) void k_forward(DevModel m, DevData d) {
+  const long e = (long)blockIdx.x * BS_BLOCK + threadIdx.x;
+  if (e >= d.n_envs) return;
+  env_forward(m, d, e);
+}
+// single stage, for per-stage timing: 0 check+position+factor, 2 velocity, 3 constraint, 4 integrate
+__global__ __launch_bounds__(BS_BLOCK) void k_stage(DevModel m, DevData d, int stage) {
+  const long e = (long)blockIdx.x * BS_BLOCK + threadIdx.x;
+  if (e >= d.n_envs) return;
+  switch (stage) {
+    case 0:
+      env_check(m, d, e, d.qpos, m.njnt, 0);
+      env_check(m, d, e, d.qvel, m.nv, 1);
+      stage_position(m, d, e);
+      stage_factor(m, d, e);
+      break;
+    case 2: stage_velocity(m, d, e); break;
+    case 3: stage_constraint(m, d, e); break;
+    case 4:
+      if (env_check(m, d, e, d.qacc, m.nv, 2)) env_forward(m, d, e);
+      if (m.integrator == 1) stage_rk4(m, d, e);
+      else stage_euler(m, d, e);
+      break;
+    default: break;
+  }
+}
+__global__ __launch_bounds__(BS_BLOCK) void k_reset(DevModel m, DevData d, const uint8_t* mask) {
+  const long e = (long)blockIdx.x * BS_BLOCK + threadIdx.x;
+  if (e >= d.n_envs) return;
+  if (mask && !mask[e]) return;
+  env_reset(m, d, e);
+  const long E = d.E;
+  AT(d.warning, 0) = 0;
+}
+// on-demand frames: xmat[9*nbody], geom_xpos[3*ngeom], geom_xmat[9*ngeom] from xpos/xquat
+__global__ __launch_bounds__(BS_BLOCK) void k_frames(DevModel m, DevData d, double* xmat, double* gpos,
+                                                     double* gmat) {
+  const long e = (long)blockIdx.x * BS_BLOCK + threadIdx.x;
+  if (e >= d.n_envs) return;
+  const long E = d.E;
+  for (int b = 0; b < m.nbody; b++) {
+    Q4 q = {AT(d.xquat, 4 * b), AT(d.xquat, 4 * b + 1), AT(d.xquat, 4 * b + 2), AT(d.xquat, 4 * b + 3)};
+    M3 R = q2m(q);
+    for (int k = 0; k < 9; k++) AT(xmat, 9 * b + k) = R.a[k];
+  }
+  for (int g = 0; g < m.ngeom; g++) {
+    const int b = m.geom_bodyid[g];
+    Q4 q = {AT(d.xquat, 4 * b), AT(d.xquat, 4 * b + 1), AT(d.xquat, 4 * b + 2), AT(d.xquat, 4 * b + 3)};
+    M3 R = q2m(q);
+    V3 p = mrot(R, ld3(m.geom_pos + 3 * g));
+    AT(gpos, 3 * g) = AT(d.xpos, 3 * b) + p.x;
+    AT(gpos, 3 * g + 1) = AT(d.xpos, 3 * b + 1) + p.y;
+    AT(gpos, 3 * g + 2) = AT(d.xpos, 3 * b + 2) + p.z;
+    M3 G = q2m(qmul(q, ld4(m.geom_quat + 4 * g)));
+    for (int k = 0; k < 9; k++) AT(gmat, 9 * g + k) = G.a[k];
+  }
+}
+
+static inline dim3 grid_for(const bs_sim* s) { return dim3((unsigned)((s->n_envs + BS_BLOCK - 1) / BS_BLOCK)); }
+
+extern "C" int bs_sim_create(const bs_model* const* models, int n_models, const int32_t* env_model_id,
+                             int64_t n_envs, int device, const bs_options* opt, bs_sim** out) {
+  (void)opt;
+  if (!models || !out || n_models < 1 || !models[0]) return fail(BS_ERR_INVALID, "bs_sim_create: null argument");
+  if (n_envs < 1) return fail(BS_ERR_INVALID, "bs_sim_create: n_envs must be >= 1 (got %lld)", (long long)n_envs);
+  if (n_models != 1)
+    return fail(BS_ERR_UNSUPPORTED, "bs_sim_create: mixed-model batches are not implemented yet (n_models=%d)",
+                n_models);
+  if (env_model_id)
+    for (int64_t i = 0; i < n_envs; i++)
+      if (env_model_id[i] != 0) return fail(BS_ERR_INVALID, "bs_sim_create: env_model_id[%lld] out of range", (long long)i);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
+    (void)hipGetLastError();
+    return fail(BS_ERR_NODEVICE, "bs_sim_create: no HIP device available (libbatchsim has no CPU fallback)");
+  }
+  if (device < 0 || device >= ndev) return fail(BS_ERR_INVALID, "bs_sim_create: device %d out of range [0,%d)", device, ndev);
+  bs_model* model = const_cast<bs_model*>(models[0]);
+  const DevModel* dmp = nullptr;
+  int rc = model_image(model, device, &dmp);
+  if (rc) return rc;
+
+  bs_sim* s = new bs_sim();
+  s->model = model; s->dm = *dmp; s->device = device; s->n_envs = n_envs;
+  s->E = (n_envs + 63) / 64 * 64;
+  const DevModel& m = s->dm;
+  const long E = s->E;
+  HIPCHK(hipSetDevice(device));
+  HIPCHK(hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking));
+  s->stream = s->own_stream;
+
+  // arena layout: all double rows, then the int rows
+  struct Slot { double** p; int rows; int field; };
+  DevData& d = s->dd;
+  memset(&d, 0, sizeof d);
+  d.E = E; d.n_envs = n_envs;
+  const int nb = m.nbody, nj = m.njnt, nv = m.nv, nu = m.nu, nM = m.nM, nrow = m.nrow;
+  Slot slots[] = {
+      {&d.qpos, nj, BS_F_QPOS}, {&d.qvel, nv, BS_F_QVEL}, {&d.ctrl, nu, BS_F_CTRL},
+      {&d.qfrc_applied, nv, BS_F_QFRC_APPLIED}, {&d.qacc, nv, BS_F_QACC},
+      {&d.qacc_warmstart, nv, BS_F_QACC_WARMSTART}, {&d.time, 1, BS_F_TIME},
+      {&d.xpos, 3 * nb, BS_F_XPOS}, {&d.xquat, 4 * nb, BS_F_XQUAT}, {&d.xipos, 3 * nb, BS_F_XIPOS},
+      {&d.xanchor, 3 * nj, BS_F_XANCHOR}, {&d.xaxis, 3 * nj, BS_F_XAXIS}, {&d.rootcom, 3 * nb, BS_F_ROOTCOM},
+      {&d.cinert, 10 * nb, BS_F_CINERT}, {&d.crb, 10 * nb, BS_F_CRB}, {&d.cdof, 6 * nv, BS_F_CDOF},
+      {&d.qM, nM, BS_F_QM}, {&d.qLD, nM, BS_F_QLD}, {&d.qLDiagInv, nv, BS_F_QLDIAGINV},
+      {&d.cvel, 6 * nb, BS_F_CVEL}, {&d.cacc, 6 * nb, -1}, {&d.cfrc, 6 * nb, -1},
+      {&d.qfrc_bias, nv, BS_F_QFRC_BIAS}, {&d.qfrc_passive, nv, BS_F_QFRC_PASSIVE},
+      {&d.actuator_force, nu, BS_F_ACTUATOR_FORCE}, {&d.qfrc_actuator, nv, BS_F_QFRC_ACTUATOR},
+      {&d.qfrc_smooth, nv, BS_F_QFRC_SMOOTH}, {&d.qacc_smooth, nv, BS_F_QACC_SMOOTH},
+      {&d.qfrc_constraint, nv, BS_F_QFRC_CONSTRAINT},
+      {&d.efc_D, nrow, BS_F_EFC_D}, {&d.efc_aref, nrow, BS_F_EFC_AREF}, {&d.efc_force, nrow, BS_F_EFC_FORCE},
+      {&d.jar, nrow, -1}, {&d.jv, nrow, -1}, {&d.eq_coef, m.neq, -1}, {&d.fric_rf, m.nfric, -1},
+      {&d.Ma, nv, -1}, {&d.grad, nv, -1}, {&d.Mgrad, nv, -1}, {&d.search, nv, -1}, {&d.Mv, nv, -1},
+      {&d.H, nM, -1}, {&d.Hdinv, nv, -1},
+      {&d.rk_q0, nj, -1}, {&d.rk_v0, nv, -1}, {&d.rk_Fv, 4 * nv, -1}, {&d.rk_Fa, 4 * nv, -1}};
+  size_t rows = 0;
+  for (auto& sl : slots) rows += (size_t)(sl.rows > 0 ? sl.rows : 1);
+  s->derived_rows = (size_t)9 * nb + (size_t)12 * (m.ngeom > 0 ? m.ngeom : 1);
+  const size_t dbl_bytes = (rows + s->derived_rows) * (size_t)E * sizeof(double);
+  const size_t int_bytes = 3 * (size_t)E * sizeof(int);
+  s->arena_bytes = dbl_bytes + int_bytes;
+  hipError_t he = hipMalloc(&s->arena, s->arena_bytes);
+  if (he != hipSuccess) {
+    (void)hipStreamDestroy(s->own_stream);
+    delete s;
+    return fail(BS_ERR_NOMEM, "bs_sim_create: hipMalloc of %zu bytes failed: %s", s->arena_bytes, hipGetErrorString(he));
+  }
+  HIPCHK(hipMemset(s->arena, 0, s->arena_bytes));
+  double* base = (double*)s->arena;
+  size_t r = 0;
+  for (auto& sl : slots) {
+    *sl.p = base + r * (size_t)E;
+    if (sl.field >= 0) { s->fields[sl.field].ptr = *sl.p; s->fields[sl.field].rows = sl.rows; }
+    r += (size_t)(sl.rows > 0 ? sl.rows : 1);
+  }
+  s->derived = base + r * (size_t)E;
+  s->fields[BS_F_XMAT] = {s->derived, 9 * nb, false};
+  s->fields[BS_F_GEOM_XPOS] = {s->derived + (size_t)9 * nb * E, 3 * m.ngeom, false};
+  s->fields[BS_F_GEOM_XMAT] = {s->derived + ((size_t)9 * nb + 3 * (size_t)m.ngeom) * E, 9 * m.ngeom, false};
+  int* ibase = (int*)((char*)s->arena + dbl_bytes);
+  d.solver_iter = ibase; d.warning = ibase + E; d.nefc = ibase + 2 * E;
+  s->fields[BS_F_SOLVER_ITER] = {d.solver_iter, 1, true};
+  s->fields[BS_F_WARNING] = {d.warning, 1, true};
+  s->fields[BS_F_NEFC] = {d.nefc, 1, true};
+  for (auto& ev : s->ev) HIPCHK(hipEventCreate(&ev));
+  s->events = true;
+  hipLaunchKernelGGL(k_reset, grid_for(s), dim3(BS_BLOCK), 0, s->stream, s->dm, s->dd, (const uint8_t*)nullptr);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(s->stream));
+  *out = s;
+  return BS_OK;
+}
+
+extern "C" int bs_sim_destroy(bs_sim* s) {
+  if (!s) return BS_OK;
+  (void)hipSetDevice(s->device);
+  (void)hipStreamSynchronize(s->stream);
+  if (s->events)
+    for (auto& ev : s->ev) (void)hipEventDestroy(ev);
+  if (s->arena) (void)hipFree(s->arena);
+  if (s->own_stream) (void)hipStreamDestroy(s->own_stream);
+  delete s;
+  return BS_OK;
+}
+
+extern "C" int bs_set_stream(bs_sim* s, void* hip_stream, int use_own_stream) {
+  if (!s) return fail(BS_ERR_INVALID, "bs_set_stream: null sim");
+  HIPCHK(hipSetDevice(s->device));
+  HIPCHK(hipStreamSynchronize(s->stream));
+  s->stream = use_own_stream ? s->own_stream : (hipStream_t)hip_stream;
+  return BS_OK;
+}
+
+extern "C" int bs_step(bs_sim* s, int n_steps) {
+  if (!s) return fail(BS_ERR_INVALID, "bs_step: null sim");
+  if (n_steps < 0) return fail(BS_ERR_INVALID, "bs_step: n_steps must be >= 0 (got %d)", n_steps);
+  if (n_steps == 0) return BS_OK;
+  HIPCHK(hipSetDevice(s->device));
+  hipLaunchKernelGGL(k_step, grid_for(s), dim3(BS_BLOCK), 0, s->stream, s->dm, s->dd, n_steps);
+  HIPCHK(hipGetLastError());
+  return BS_OK;
+}
+
+extern "C" int bs_forward(bs_sim* s) {
+  if (!s) return fail(BS_ERR_INVALID, "bs_forward: null sim");
+  HIPCHK(hipSetDevice(s->device));
+  hipLaunchKernelGGL(k_forward, grid_for(s), dim3(BS_BLOCK), 0, s->stream, s->dm, s->dd);
+  HIPCHK(hipGetLastError());
+  return BS_OK;
+}
+
+extern "C" int bs_reset(bs_sim* s, const uint8_t* env_mask) {
+  if (!s) return fail(BS_ERR_INVALID, "bs_reset: null sim");
+  HIPCHK(hipSetDevice(s->device));
+  uint8_t* dmask = nullptr;
+  if (env_mask) {
+    HIPCHK(hipMalloc((void**)&dmask, (size_t)s->n_envs));
+    HIPCHK(hipMemcpyAsync(dmask, env_mask, (size_t)s->n_envs, hipMemcpyHostToDevice, s->stream));
+  }
+  hipLaunchKernelGGL(k_reset, grid_for(s), dim3(BS_BLOCK), 0, s->stream, s->dm, s->dd, (const uint8_t*)dmask);
+  HIPCHK(hipGetLastError());
+  if (dmask) {
+    HIPCHK(hipStreamSynchronize(s->stream));
+    HIPCHK(hipFree(dmask));
+  }
+  return BS_OK;
+}
+
+static int refresh_derived(bs_sim* s) {
+  hipLaunchKernelGGL(k_frames, grid_for(s), dim3(BS_BLOCK), 0, s->stream, s->dm, s->dd,
+                     (double*)s->fields[BS_F_XMAT].ptr, (double*)s->fields[BS_F_GEOM_XPOS].ptr,
+                     (double*)s->fields[BS_F_GEOM_XMAT].ptr);
+  HIPCHK(hipGetLastError());
+  return BS_OK;
+}
+
+extern "C" int bs_get_ptr(bs_sim* s, int field_id, void** dev_ptr, int64_t shape[2], int64_t stride[2],
+                          int* is_int32) {
+  if (!s || !dev_ptr || !shape || !stride) return fail(BS_ERR_INVALID, "bs_get_ptr: null argument");
+  if (field_id < 0 || field_id >= BS_F_COUNT) return fail(BS_ERR_INVALID, "bs_get_ptr: unknown field %d", field_id);
+  HIPCHK(hipSetDevice(s->device));
+  if (field_id == BS_F_XMAT || field_id == BS_F_GEOM_XPOS || field_id == BS_F_GEOM_XMAT) {
+    int rc = refresh_derived(s);
+    if (rc) return rc;
+  }
+  const FieldInfo& f = s->fields[field_id];
+  *dev_ptr = f.ptr;
+  shape[0] = f.rows; shape[1] = s->n_envs;
+  stride[0] = s->E; stride[1] = 1;
+  if (is_int32) *is_int32 = f.is_int ? 1 : 0;
+  return BS_OK;
+}
+
+extern "C" int bs_copy_field(bs_sim* s, int field_id, void* host, int direction) {
+  if (!s || !host) return fail(BS_ERR_INVALID, "bs_copy_field: null argument");
+  if (field_id < 0 || field_id >= BS_F_COUNT) return fail(BS_ERR_INVALID, "bs_copy_field: unknown field %d", field_id);
+  if (direction != 0 && direction != 1) return fail(BS_ERR_INVALID, "bs_copy_field: direction must be 0 or 1");
+  HIPCHK(hipSetDevice(s->device));
+  const bool derived = field_id == BS_F_XMAT || field_id == BS_F_GEOM_XPOS || field_id == BS_F_GEOM_XMAT;
+  if (derived) {
+    if (direction == 1) return fail(BS_ERR_INVALID, "bs_copy_field: field %d is read-only", field_id);
+    int rc = refresh_derived(s);
+    if (rc) return rc;
+  }
+  const FieldInfo& f = s->fields[field_id];
+  if (f.rows == 0) return BS_OK;
+  const size_t esz = f.is_int ? sizeof(int) : sizeof(double);
+  HIPCHK(hipStreamSynchronize(s->stream));
+  if (direction == 0)
+    HIPCHK(hipMemcpy2D(host, (size_t)s->n_envs * esz, f.ptr, (size_t)s->E * esz, (size_t)s->n_envs * esz,
+                       (size_t)f.rows, hipMemcpyDeviceToHost));
+  else
+    HIPCHK(hipMemcpy2D(f.ptr, (size_t)s->E * esz, host, (size_t)s->n_envs * esz, (size_t)s->n_envs * esz,
+                       (size_t)f.rows, hipMemcpyHostToDevice));
+  return BS_OK;
+}
+
+extern "C" int bs_get_contacts(bs_sim* s, int64_t env, int32_t* geom1, int32_t* geom2, double* dist, int cap,
+                               int* n) {
+  (void)geom1; (void)geom2; (void)dist; (void)cap;
+  if (!s || !n) return fail(BS_ERR_INVALID, "bs_get_contacts: null argument");
+  if (env < 0 || env >= s->n_envs) return fail(BS_ERR_INVALID, "bs_get_contacts: env %lld out of range", (long long)env);
+  *n = 0;  // the collision stage (A5/A6) is not on the device yet: contact-free step only
+  return BS_OK;
+}
+
+extern "C" int bs_sync(bs_sim* s) {
+  if (!s) return fail(BS_ERR_INVALID, "bs_sync: null sim");
+  HIPCHK(hipSetDevice(s->device));
+  HIPCHK(hipStreamSynchronize(s->stream));
+  return BS_OK;
+}
+
+extern "C" int bs_stage_times(bs_sim* s, double* ms, int n) {
+  if (!s || !ms || n < 5) return fail(BS_ERR_INVALID, "bs_stage_times: need room for 5 stage times");
+  HIPCHK(hipSetDevice(s->device));
+  const int stages[4] = {0, 2, 3, 4};
+  HIPCHK(hipEventRecord(s->ev[0], s->stream));
+  for (int k = 0; k < 4; k++) {
+    hipLaunchKernelGGL(k_stage, grid_for(s), dim3(BS_BLOCK), 0, s->stream, s->dm, s->dd, stages[k]);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(s->ev[k + 1], s->stream));
+  }
+  HIPCHK(hipEventSynchronize(s->ev[4]));
+  float t[4];
+  for (int k = 0; k < 4; k++) HIPCHK(hipEventElapsedTime(&t[k], s->ev[k], s->ev[k + 1]));
+  ms[0] = t[0]; ms[1] = 0.0; ms[2] = t[1]; ms[3] = t[2]; ms[4] = t[3];
+  return BS_OK;
+}
+
+extern "C" int bs_timed_steps(bs_sim* s, int n_steps, double* elapsed_ms) {
+  if (!s || !elapsed_ms) return fail(BS_ERR_INVALID, "bs_timed_steps: null argument");
+  if (n_steps < 1) return fail(BS_ERR_INVALID, "bs_timed_steps: n_steps must be >= 1");
+  HIPCHK(hipSetDevice(s->device));
+  HIPCHK(hipEventRecord(s->ev[5], s->stream));
+  for (int k = 0; k < n_steps; k++) {
+    hipLaunchKernelGGL(k_step, grid_for(s), dim3(BS_BLOCK), 0, s->stream, s->dm, s->dd, 1);
+  }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(s->ev[6], s->stream));
+  HIPCHK(hipEventSynchronize(s->ev[6]));
+  float t = 0;
+  HIPCHK(hipEventElapsedTime(&t, s->ev[5], s->ev[6]));
+  *elapsed_ms = t;
+  return BS_OK;
+}

@@ -1,0 +1,223 @@
+"""BatchSim — the mujoco-py `MjSim` surface over libbatchsim.so.
+
+Mirrors what the reference builds at src/Mujoco_XML.py:341-342 (`load_model_from_xml` ->
+`MjSim(model)`) and what BASELINE.json's north_star names (`sim.step()`,
+`sim.data.qpos/qvel/ctrl`), for `n_envs` lockstep environments on one MI355X.
+
+`sim.data.<field>` are zero-copy torch views of the library's device arrays, shaped
+`[n_envs, ...]` (for n_envs == 1 the leading axis is dropped, giving mujoco-py's shapes).
+PyTorch is used only as the device-array / stream plumbing; all physics runs in the HIP
+kernels behind the C-ABI (include/batchsim.h).  There is no CPU fallback.
+"""
+import ctypes as C
+from collections import namedtuple
+
+import numpy as np
+
+from . import _abi
+from ._abi import BatchSimError  # noqa: F401
+
+MjSimState = namedtuple("MjSimState", "time qpos qvel act udd_state")
+
+# field -> trailing shape (as a function of the model) for reshaping [E, rows]
+_SHAPES = {
+    "xpos": lambda m: (m.nbody, 3), "xquat": lambda m: (m.nbody, 4), "xipos": lambda m: (m.nbody, 3),
+    "xmat": lambda m: (m.nbody, 9), "xanchor": lambda m: (m.njnt, 3), "xaxis": lambda m: (m.njnt, 3),
+    "geom_xpos": lambda m: (m.ngeom, 3), "geom_xmat": lambda m: (m.ngeom, 9),
+    "cinert": lambda m: (m.nbody, 10), "crb": lambda m: (m.nbody, 10), "cdof": lambda m: (m.nv, 6),
+    "cvel": lambda m: (m.nbody, 6), "rootcom": lambda m: (m.nbody, 3),
+}
+_SCALARS = ("time", "solver_iter", "warning", "nefc")
+
+
+class _DevArray:
+    """Bare __cuda_array_interface__ carrier for a library-owned device buffer."""
+
+    def __init__(self, ptr, shape, strides, typestr):
+        self.__cuda_array_interface__ = dict(shape=tuple(shape), strides=tuple(strides), typestr=typestr,
+                                             data=(int(ptr), False), version=2)
+
+
+class NativeModel:
+    """Owner of a `bs_model*` handle."""
+
+    def __init__(self, model):
+        self.model = model
+        desc, keep = _abi.make_desc(model)
+        h = C.c_void_p()
+        _abi.check(_abi.lib().bs_model_create(C.byref(desc), C.byref(h)))
+        del keep
+        self.handle = h
+
+    def __del__(self):
+        try:
+            if self.handle:
+                _abi.lib().bs_model_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+class BatchData:
+    """`sim.data` — device views named after mjData members."""
+
+    def __init__(self, sim):
+        object.__setattr__(self, "_sim", sim)
+        object.__setattr__(self, "_cache", {})
+
+    def _view(self, name):
+        sim = self._sim
+        fid = _abi.FIELD_ID[name]
+        derived = name in ("xmat", "geom_xpos", "geom_xmat")
+        if name in self._cache and not derived:
+            return self._cache[name]
+        import torch
+        ptr = C.c_void_p()
+        shape = (C.c_int64 * 2)()
+        stride = (C.c_int64 * 2)()
+        is_int = C.c_int()
+        _abi.check(_abi.lib().bs_get_ptr(sim._h, fid, C.byref(ptr), shape, stride, C.byref(is_int)))
+        if name in self._cache:
+            return self._cache[name]  # derived: the call above refreshed the buffer in place
+        rows, n = int(shape[0]), int(shape[1])
+        esz = 4 if is_int.value else 8
+        if rows == 0 or ptr.value is None:
+            t = torch.zeros((n, 0), dtype=torch.int32 if is_int.value else torch.float64,
+                            device=f"cuda:{sim.device_id}")
+        else:
+            arr = _DevArray(ptr.value, (rows, n), (int(stride[0]) * esz, int(stride[1]) * esz),
+                            "<i4" if is_int.value else "<f8")
+            t = torch.as_tensor(arr, device=f"cuda:{sim.device_id}").T  # [n_envs, rows]
+        m = sim.model
+        if name in _SHAPES:
+            t = t.unflatten(1, _SHAPES[name](m))
+        elif name in _SCALARS:
+            t = t[:, 0]
+        if sim.n_envs == 1 and name not in _SCALARS:
+            t = t[0]
+        self._cache[name] = t
+        return t
+
+    def __getattr__(self, name):
+        if name in _abi.FIELD_ID:
+            return self._view(name)
+        if name == "ncon":
+            import torch
+            return torch.zeros(self._sim.n_envs, dtype=torch.int32, device=f"cuda:{self._sim.device_id}")
+        if name == "subtree_com":
+            return self._view("rootcom")
+        raise AttributeError(name)
+
+    def __setattr__(self, name, value):
+        if name in _abi.FIELD_ID:
+            import torch
+            self._view(name).copy_(torch.as_tensor(value))
+        else:
+            raise AttributeError(f"cannot set {name}")
+
+    def to_host(self, name):
+        """Dense NumPy copy `[rows, n_envs]` of a field via bs_copy_field (synchronises)."""
+        sim = self._sim
+        fid = _abi.FIELD_ID[name]
+        ptr = C.c_void_p()
+        shape = (C.c_int64 * 2)()
+        stride = (C.c_int64 * 2)()
+        is_int = C.c_int()
+        _abi.check(_abi.lib().bs_get_ptr(sim._h, fid, C.byref(ptr), shape, stride, C.byref(is_int)))
+        out = np.zeros((int(shape[0]), int(shape[1])), dtype=np.int32 if is_int.value else np.float64)
+        _abi.check(_abi.lib().bs_copy_field(sim._h, fid, out.ctypes.data_as(C.c_void_p), 0))
+        return out
+
+    def from_host(self, name, arr):
+        sim = self._sim
+        fid = _abi.FIELD_ID[name]
+        a = np.ascontiguousarray(arr)
+        _abi.check(_abi.lib().bs_copy_field(sim._h, fid, a.ctypes.data_as(C.c_void_p), 1))
+
+
+class BatchSim:
+    """`MjSim(model, nsubsteps=1)` for `n_envs` environments stepped in lockstep on one GPU."""
+
+    def __init__(self, model, n_envs=1, device_id=0, nsubsteps=1, use_torch_stream=True):
+        if n_envs < 1:
+            raise ValueError("n_envs must be >= 1")
+        if nsubsteps < 1:
+            raise ValueError("nsubsteps must be >= 1")
+        L = _abi.lib()
+        self.model = model
+        self.n_envs = int(n_envs)
+        self.device_id = int(device_id)
+        self.nsubsteps = int(nsubsteps)
+        self._native = model if isinstance(model, NativeModel) else NativeModel(model)
+        if isinstance(model, NativeModel):
+            self.model = model.model
+        h = C.c_void_p()
+        models = (C.c_void_p * 1)(self._native.handle)
+        _abi.check(L.bs_sim_create(models, 1, None, self.n_envs, self.device_id, None, C.byref(h)))
+        self._h = h
+        self.data = BatchData(self)
+        if use_torch_stream:
+            import torch
+            with torch.cuda.device(self.device_id):
+                st = torch.cuda.current_stream().cuda_stream
+            _abi.check(L.bs_set_stream(self._h, C.c_void_p(st), 0))
+
+    # -- lifecycle
+    def close(self):
+        if getattr(self, "_h", None):
+            _abi.lib().bs_sim_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- MjSim surface
+    def step(self, n=None):
+        _abi.check(_abi.lib().bs_step(self._h, self.nsubsteps if n is None else int(n)))
+
+    def forward(self):
+        _abi.check(_abi.lib().bs_forward(self._h))
+
+    def reset(self, env_mask=None):
+        if env_mask is None:
+            _abi.check(_abi.lib().bs_reset(self._h, None))
+        else:
+            mk = np.ascontiguousarray(np.asarray(env_mask).astype(np.uint8))
+            if mk.shape != (self.n_envs,):
+                raise ValueError("env_mask must have shape (n_envs,)")
+            _abi.check(_abi.lib().bs_reset(self._h, mk.ctypes.data_as(C.POINTER(C.c_uint8))))
+
+    def sync(self):
+        _abi.check(_abi.lib().bs_sync(self._h))
+
+    def get_state(self):
+        d = self.data
+        return MjSimState(d.time.clone(), d.qpos.clone(), d.qvel.clone(), None, {})
+
+    def set_state(self, state):
+        d = self.data
+        d.time.copy_(state.time if hasattr(state.time, "shape") else d.time.new_full(d.time.shape, state.time))
+        d.qpos.copy_(state.qpos)
+        d.qvel.copy_(state.qvel)
+
+    def stage_times(self):
+        ms = (C.c_double * 5)()
+        _abi.check(_abi.lib().bs_stage_times(self._h, ms, 5))
+        return dict(position=ms[0], collision=ms[1], velocity=ms[2], constraint=ms[3], integrate=ms[4])
+
+    def timed_steps(self, n):
+        ms = C.c_double()
+        _abi.check(_abi.lib().bs_timed_steps(self._h, int(n), C.byref(ms)))
+        return ms.value
+
+
+MjSim = BatchSim

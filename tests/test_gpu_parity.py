@@ -1,0 +1,206 @@
+"""GPU parity tests proper: the HIP path (through the C-ABI) against the CPU oracle on the
+same seeded inputs.  PARITY UNPINNED vs MuJoCo 2.1.0: the oracle is the
+in-repo restatement; tolerances are BASELINE.json's north_star tolerances."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_forward(model, q, v, c, fields, steps=0, warm=None):
+    from oracle import OracleSim
+    s = OracleSim(model)
+    s.qpos[:] = q
+    s.qvel[:] = v
+    s.ctrl[:] = c
+    if warm is not None:
+        s.qacc_warmstart[:] = warm
+    if steps:
+        s.step(steps)
+    else:
+        s.forward()
+    return {f: np.array(getattr(s, f)).copy() for f in fields}, s
+
+
+@pytest.fixture(scope="module")
+def setup(hand_model):
+    import torch
+    from mujoco_amd import BatchSim, workload
+    assert torch.cuda.is_available()
+    m = workload.contact_free(hand_model)
+    E = 256
+    q, v = workload.config2_state(m, E, seed=1234)
+    rng = np.random.default_rng(7)
+    v = rng.normal(size=v.shape) * 0.5
+    c = workload.config2_ctrl(m, E, seed=1234)
+    sim = BatchSim(m, n_envs=E)
+    sim.data.qpos.copy_(torch.as_tensor(q))
+    sim.data.qvel.copy_(torch.as_tensor(v))
+    sim.data.ctrl.copy_(torch.as_tensor(c))
+    sim.forward()
+    sim.sync()
+    return m, sim, q, v, c
+
+
+def test_kinematics_1e12(setup):
+    """xpos / xquat to 1e-12 relative (north_star tolerance for kinematics)."""
+    m, sim, q, v, c = setup
+    xpos = sim.data.xpos.cpu().numpy()
+    xquat = sim.data.xquat.cpu().numpy()
+    xmat = sim.data.xmat.cpu().numpy()
+    gx = sim.data.geom_xpos.cpu().numpy()
+    for e in range(0, len(q), 17):
+        ref, _ = _oracle_forward(m, q[e], v[e], c[e], ["xpos", "xquat", "xmat", "geom_xpos"])
+        scale = np.abs(ref["xpos"]).max()
+        assert np.abs(xpos[e] - ref["xpos"]).max() <= 1e-12 * scale
+        assert np.abs(xquat[e] - ref["xquat"]).max() <= 1e-12
+        assert np.abs(xmat[e] - ref["xmat"]).max() <= 1e-12
+        assert np.abs(gx[e] - ref["geom_xpos"]).max() <= 1e-12 * scale
+
+
+def test_mass_matrix_and_bias(setup):
+    m, sim, q, v, c = setup
+    qM = sim.data.qM.cpu().numpy()
+    qLD = sim.data.qLD.cpu().numpy()
+    bias = sim.data.qfrc_bias.cpu().numpy()
+    smooth = sim.data.qacc_smooth.cpu().numpy()
+    af = sim.data.actuator_force.cpu().numpy()
+    for e in range(0, len(q), 17):
+        ref, _ = _oracle_forward(m, q[e], v[e], c[e], ["qM", "qLD", "qfrc_bias", "qacc_smooth", "actuator_force"])
+        assert np.abs(qM[e] - ref["qM"]).max() <= 1e-12 * np.abs(ref["qM"]).max()
+        assert np.abs(qLD[e] - ref["qLD"]).max() <= 1e-10 * np.abs(ref["qLD"]).max()
+        assert np.abs(bias[e] - ref["qfrc_bias"]).max() <= 1e-12 * max(1e-3, np.abs(ref["qfrc_bias"]).max())
+        assert np.abs(af[e] - ref["actuator_force"]).max() <= 1e-12
+        assert np.abs(smooth[e] - ref["qacc_smooth"]).max() <= 1e-9 * max(1.0, np.abs(ref["qacc_smooth"]).max())
+
+
+def test_qacc_1e8(setup):
+    """qacc after the constraint solve within 1e-8 (relative to max(1,|qacc|))."""
+    m, sim, q, v, c = setup
+    qacc = sim.data.qacc.cpu().numpy()
+    nefc = sim.data.nefc.cpu().numpy()
+    it = sim.data.solver_iter.cpu().numpy()
+    worst = 0.0
+    for e in range(0, len(q), 5):
+        ref, s = _oracle_forward(m, q[e], v[e], c[e], ["qacc", "qfrc_constraint"])
+        assert nefc[e] == s.nefc
+        err = np.abs(qacc[e] - ref["qacc"]).max() / max(1.0, np.abs(ref["qacc"]).max())
+        worst = max(worst, err)
+        assert abs(int(it[e]) - s.solver_iter) <= 1
+    assert worst <= 1e-8, worst
+
+
+def test_trajectory_1e6(hand_model):
+    """contact-free trajectory within 1e-6 of the oracle over 1000 steps, ctrl resampled
+    every 50 steps (configs[1] protocol)."""
+    import torch
+    from mujoco_amd import BatchSim, workload
+    from oracle import OracleSim
+    m = workload.contact_free(hand_model)
+    E = 64
+    q, v = workload.config2_state(m, E, seed=99)
+    sim = BatchSim(m, n_envs=E)
+    sim.data.qpos.copy_(torch.as_tensor(q))
+    sim.data.qvel.copy_(torch.as_tensor(v))
+    check = [0, 13, 63]
+    orc = []
+    for e in check:
+        s = OracleSim(m)
+        s.qpos[:] = q[e]
+        s.qvel[:] = v[e]
+        orc.append(s)
+    for k in range(20):
+        c = workload.config2_ctrl(m, E, seed=99, resample_idx=k)
+        sim.data.ctrl.copy_(torch.as_tensor(c))
+        sim.step(50)
+        for s, e in zip(orc, check):
+            s.ctrl[:] = c[e]
+            s.step(50)
+    sim.sync()
+    qg = sim.data.qpos.cpu().numpy()
+    vg = sim.data.qvel.cpu().numpy()
+    tg = sim.data.time.cpu().numpy()
+    assert sim.data.warning.cpu().numpy().max() == 0
+    for s, e in zip(orc, check):
+        assert np.abs(qg[e] - s.qpos).max() <= 1e-6
+        assert np.abs(vg[e] - s.qvel).max() <= 1e-5
+        assert abs(tg[e] - s.time) < 1e-9
+
+
+def test_default_state_golden(hand_model):
+    """BASELINE.json configs[0]: default state, zero ctrl, 1000 steps, single env, against
+    the committed oracle trajectory (self-generated fixture)."""
+    import os
+    from conftest import GOLDEN
+    from mujoco_amd import BatchSim, workload
+    g = np.load(os.path.join(GOLDEN, "dexterous_oracle_traj.npz"))
+    m = workload.contact_free(hand_model)
+    sim = BatchSim(m, n_envs=1)
+    for k in range(10):
+        sim.step(100)
+        sim.sync()
+        assert np.abs(sim.data.qpos.cpu().numpy() - g["qpos"][k]).max() <= 1e-6
+        assert np.abs(sim.data.qvel.cpu().numpy() - g["qvel"][k]).max() <= 1e-5
+
+
+def test_rk4_matches_oracle(hand_model):
+    import torch
+    from mujoco_amd import BatchSim, workload
+    from oracle import OracleSim
+    m = workload.contact_free(hand_model)
+    m.opt_integrator = 1
+    E = 64
+    q, v = workload.config2_state(m, E, seed=5)
+    c = workload.config2_ctrl(m, E, seed=5)
+    sim = BatchSim(m, n_envs=E)
+    sim.data.qpos.copy_(torch.as_tensor(q))
+    sim.data.ctrl.copy_(torch.as_tensor(c))
+    sim.step(100)
+    sim.sync()
+    qg = sim.data.qpos.cpu().numpy()
+    for e in (0, 31):
+        s = OracleSim(m)
+        s.qpos[:] = q[e]
+        s.ctrl[:] = c[e]
+        s.step(100)
+        assert np.abs(qg[e] - s.qpos).max() <= 1e-7
+
+
+def test_ragged_env_count_and_reset(hand_model):
+    """n_envs not a multiple of the 64-lane wave; masked reset; NaN guard (A14)."""
+    import torch
+    from mujoco_amd import BatchSim, workload
+    m = workload.contact_free(hand_model)
+    E = 70
+    q, v = workload.config2_state(m, E, seed=3)
+    sim = BatchSim(m, n_envs=E)
+    sim.data.qpos.copy_(torch.as_tensor(q))
+    sim.step(10)
+    mask = np.zeros(E, dtype=np.uint8)
+    mask[[1, 69]] = 1
+    sim.reset(mask)
+    sim.sync()
+    qp = sim.data.qpos.cpu().numpy()
+    assert np.all(qp[1] == 0) and np.all(qp[69] == 0) and np.abs(qp[0]).max() > 0
+    sim.data.qpos[5, 3] = float("nan")
+    sim.step(1)
+    sim.sync()
+    w = sim.data.warning.cpu().numpy()
+    assert w[5] & 1 and w[4] == 0
+    assert np.isfinite(sim.data.qpos.cpu().numpy()).all()
+    # host copies through bs_copy_field agree with the zero-copy views
+    assert np.array_equal(sim.data.to_host("qpos").T, sim.data.qpos.cpu().numpy())
+
+
+def test_error_behaviour(hand_model):
+    from mujoco_amd import BatchSim, BatchSimError, workload
+    m = workload.contact_free(hand_model)
+    with pytest.raises(ValueError):
+        BatchSim(m, n_envs=0)
+    sim = BatchSim(m, n_envs=1)
+    with pytest.raises(BatchSimError):
+        sim.step(-1)
+    bad = m.copy()
+    bad.opt_solver = 0
+    with pytest.raises(BatchSimError):
+        BatchSim(bad, n_envs=1)
