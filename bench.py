@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""bench.py — env-steps/s of the batched physics step (BASELINE.json metric).
+
+Workload (N=1): BASELINE.json configs[1] — DexterousDynamos.xml joint-space only (contacts
+disabled), 4096 lockstep envs on one MI355X, random ctrl resampled every 50 steps, fp64.
+A "step" is one mj_step of the whole batch.  State and the ctrl bank are resident in HBM before
+the timed region.  N>1 (launched by torch.distributed.run): each rank steps its own 4096 envs
+(weak scaling, no traffic inside a step) and, once per control period (50 steps), all-gathers
+obs (qpos|qvel, fp32) + reward over RCCL for a centralised learner.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_PER_ENV_STEP = 36.0e3      # contact-free, Euler, Newton (algorithmic fp64 flop)
+BYTES_PER_ENV_STEP = 1.3e3      # compulsory HBM bytes per env-step
+FP64_PEAK_TFLOPS = 78.6         # MI355X fp64 vector == fp64 matrix peak (datasheet [EXT])
+CTRL_PERIOD = 50
+
+
+def cpu_baseline(model, seconds_budget=12.0):
+    """Oracle (CPU restatement, kind 'port') on this host: single thread, then all cores."""
+    from mujoco_amd import workload
+    from oracle import OracleSim
+    n_envs, n_steps = 64, 1000
+    q, v = workload.config2_state(model, n_envs, seed=1234)
+    c = workload.config2_ctrl(model, n_envs, seed=1234)
+    sims = []
+    for e in range(n_envs):
+        s = OracleSim(model)
+        s.qpos[:] = q[e]
+        s.ctrl[:] = c[e]
+        sims.append(s)
+    t0 = time.perf_counter()
+    done = 0
+    for s in sims:
+        s.step(n_steps)
+        done += n_steps
+        if time.perf_counter() - t0 > seconds_budget:
+            break
+    dt = time.perf_counter() - t0
+    return dict(value=done / dt, unit="env-steps/s", cores=1, kind="port",
+                sample=f"{done // n_steps} envs x {n_steps} steps of the same workload "
+                       f"(oracle/liboracle.so, gcc -O2, single thread, {dt:.1f} s)")
+
+
+def _pool_worker(args):
+    path, seed, n_envs, n_steps = args
+    sys.path.insert(0, ROOT)
+    from mujoco_amd import Model, workload
+    from oracle import OracleSim
+    model = workload.contact_free(Model.load(path))
+    q, v = workload.config2_state(model, n_envs, seed=seed)
+    c = workload.config2_ctrl(model, n_envs, seed=seed)
+    t0 = time.perf_counter()
+    for e in range(n_envs):
+        s = OracleSim(model)
+        s.qpos[:] = q[e]
+        s.ctrl[:] = c[e]
+        s.step(n_steps)
+    return n_envs * n_steps, time.perf_counter() - t0
+
+
+def cpu_baseline_allcores(model_path):
+    import multiprocessing as mp
+    cores = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16") or 16), 16)
+    n_envs, n_steps = 32, 1000
+    ctx = mp.get_context("spawn")
+    t0 = time.perf_counter()
+    with ctx.Pool(cores) as pool:
+        res = pool.map(_pool_worker, [(model_path, 1234 + i, n_envs, n_steps) for i in range(cores)])
+    wall = time.perf_counter() - t0
+    work = sum(r[0] for r in res)
+    inner = max(r[1] for r in res)
+    return dict(value=work / inner, unit="env-steps/s", cores=cores, kind="port",
+                sample=f"{cores} processes x {n_envs} envs x {n_steps} steps (slowest worker {inner:.1f} s, "
+                       f"pool wall {wall:.1f} s incl. spawn)")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--envs", type=int, default=4096, help="environments per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    from mujoco_amd import BatchSim, Model, workload
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the product path")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+
+    model_path = os.path.join(ROOT, "tests", "golden", "dexterous_model.npz")
+    model = workload.contact_free(Model.load(model_path))
+    E = args.envs
+    seed = 1234 + 1000 * rank
+    q, v = workload.config2_state(model, E, seed=seed)
+    sim = BatchSim(model, n_envs=E, device_id=local_rank)
+    dev = f"cuda:{local_rank}"
+    sim.data.qpos.copy_(torch.as_tensor(q))
+    sim.data.qvel.copy_(torch.as_tensor(v))
+    n_bank = 8
+    bank = torch.as_tensor(np.stack([workload.config2_ctrl(model, E, seed=seed, resample_idx=k)
+                                     for k in range(n_bank)])).to(dev)
+
+    from mujoco_amd import dist as bdist
+    gather = bdist.ObsGather(sim, world) if world > 1 else None
+
+    def run(nsteps, start_period):
+        done, period = 0, start_period
+        while done < nsteps:
+            n = min(CTRL_PERIOD, nsteps - done)
+            sim.data.ctrl.copy_(bank[period % n_bank])
+            sim.step(n)
+            if gather is not None:
+                gather.all_gather()
+            done += n
+            period += 1
+        return period
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    period = run(args.warmup, 0)
+    fence()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    run(args.steps, period)
+    ev1.record()
+    fence()
+    wall = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([wall], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+    gpu_ms = ev0.elapsed_time(ev1)  # same stream as the kernels (BatchSim uses torch's current stream)
+    warn = int((sim.data.warning != 0).sum().item())
+    iters = float(sim.data.solver_iter.double().mean().item())
+    nefc = float(sim.data.nefc.double().mean().item())
+
+    # kernel-only timing with HIP events on the kernel's stream, inside the library: k_step
+    # launches of CTRL_PERIOD steps each (what the timed loop issues)
+    n_launch = 10
+    sim.data.ctrl.copy_(bank[0])
+    kms = []
+    for _ in range(n_launch):
+        ev0.record()
+        sim.step(CTRL_PERIOD)
+        ev1.record()
+        ev1.synchronize()
+        kms.append(ev0.elapsed_time(ev1))
+    k_ms = float(np.mean(kms))
+    stage = sim.stage_times()
+
+    if rank == 0:
+        value = E * world * args.steps / wall
+        flops_launch = FLOP_PER_ENV_STEP * E * CTRL_PERIOD
+        achieved = flops_launch / (k_ms * 1e-3) / 1e12
+        out = {
+            "metric": "env-steps/sec", "value": value, "unit": "env-steps/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall * 1e3 / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[1]: DexterousDynamos.xml joint-space only "
+                                   "(contacts disabled), lockstep envs, random ctrl resampled every 50 steps, "
+                                   "Euler + Newton, fp64",
+                       "n_envs_per_gpu": E, "n_envs_total": E * world, "ctrl_period": CTRL_PERIOD,
+                       "collective": "RCCL all_gather obs[E,42]+reward fp32 per ctrl period" if world > 1 else "none",
+                       "mean_solver_iter": iters, "mean_nefc": nefc, "envs_with_warnings": warn},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None,
+                         "kernel": "k_step", "launch_ms": k_ms, "env_steps_per_launch": E * CTRL_PERIOD,
+                         "flop_per_env_step": FLOP_PER_ENV_STEP,
+                         "note": "fp64 compute-bound path: peak is the MI355X fp64 vector=matrix rate; "
+                                 "algorithmic HBM rate would be "
+                                 f"{BYTES_PER_ENV_STEP * E * CTRL_PERIOD / (k_ms * 1e-3) / 1e9:.2f} GB/s of 8000"},
+            "gpu_event_ms_per_step": gpu_ms / args.steps,
+            "stage_ms_one_step": stage,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(model)
+            try:
+                out["cpu_baseline_allcores"] = cpu_baseline_allcores(model_path)
+            except Exception as ex:  # the pool is informational; the single-thread figure is the contract
+                out["cpu_baseline_allcores"] = {"error": repr(ex)}
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

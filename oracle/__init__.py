@@ -212,7 +212,7 @@ class OracleSim:
             return np.ctypeslib.as_array(getattr(d, "efc_" + name), shape=(d.nefc_max,))[:n].copy()
         w = {"J": self.model.nv, "KBIP": 4}.get(name, 1)
         a = np.ctypeslib.as_array(getattr(d, "efc_" + name), shape=(d.nefc_max * w,))[:n * w].copy()
-        return a.reshape(n, w) if w > 1 else a
+        return a.reshape(n, w) if name in ("J", "KBIP") else a
 
     def contacts(self):
         d = self._d.contents

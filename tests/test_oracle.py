@@ -1,0 +1,201 @@
+"""The CPU oracle (oracle/) against independent formulations: the reference holds no golden
+vectors for dynamics (PARITY UNPINNED), so the oracle is pinned by identities
+and third-opinion computations, plus its own committed trajectory fixture."""
+import os
+
+import numpy as np
+import pytest
+
+from mujoco_amd import workload
+from mujoco_amd.model import host_fk, host_jac, host_mass_matrix
+from oracle import OracleSim
+from conftest import GOLDEN
+
+
+@pytest.fixture(scope="module")
+def cf_model(hand_model):
+    return workload.contact_free(hand_model)
+
+
+def _random_state(m, seed):
+    rng = np.random.default_rng(seed)
+    lo, hi = m.jnt_range[:, 0], m.jnt_range[:, 1]
+    return lo + rng.random(m.nq) * (hi - lo), rng.normal(size=m.nv)
+
+
+def test_fk_mass_matrix_vs_jacobian_formulation(cf_model):
+    m = cf_model
+    for seed in range(5):
+        q, v = _random_state(m, seed)
+        s = OracleSim(m)
+        s.qpos[:] = q
+        s.forward()
+        fk = host_fk(m, q)
+        assert np.abs(s.xpos - fk["xpos"]).max() < 1e-15
+        assert np.abs(s.xquat - fk["xquat"]).max() < 1e-14
+        assert np.abs(s.xmat.reshape(-1, 3, 3) - fk["xmat"]).max() < 1e-14
+        M = host_mass_matrix(m, fk)          # sum_b m Jp^T Jp + Jr^T I Jr  (not CRB)
+        Mo = s.full_m()
+        assert np.abs(Mo - M).max() < 1e-15
+        assert np.allclose(Mo, Mo.T) and np.linalg.eigvalsh(Mo).min() > 0
+        x = np.random.default_rng(seed).normal(size=m.nv)
+        assert np.abs(s.solve_m(x) - np.linalg.solve(M, x)).max() < 1e-9 * np.abs(np.linalg.solve(M, x)).max()
+        assert np.abs(s.mul_m(x) - M @ x).max() < 1e-16 + 1e-14 * np.abs(M @ x).max()
+
+
+def test_bias_forces_vs_lagrangian(cf_model):
+    """qfrc_bias = C(q,v) + G(q): G from body Jacobians, C from finite-differenced M."""
+    m = cf_model
+    q, v = _random_state(m, 3)
+    s = OracleSim(m)
+    s.qpos[:] = q
+    s.qvel[:] = v
+    s.forward()
+    fk = host_fk(m, q)
+    G = np.zeros(m.nv)
+    for b in range(1, m.nbody):
+        jp, _ = host_jac(m, fk, b, fk["xipos"][b])
+        G -= m.body_mass[b] * jp.T @ m.opt_gravity
+    h = 1e-6
+    dM = []
+    for k in range(m.nv):
+        qp, qm = q.copy(), q.copy()
+        qp[k] += h
+        qm[k] -= h
+        dM.append((host_mass_matrix(m, host_fk(m, qp)) - host_mass_matrix(m, host_fk(m, qm))) / (2 * h))
+    dM = np.array(dM)  # [k, i, j] = dM_ij/dq_k
+    C = np.einsum("kij,k,j->i", dM, v, v) - 0.5 * np.einsum("iab,a,b->i", dM, v, v)
+    # armature contributes nothing to C; compare
+    assert np.abs(s.qfrc_bias - (C + G)).max() < 1e-9
+    # rne with acceleration: M qacc + bias
+    s.qacc[:] = np.linspace(-1, 1, m.nv)
+    full = s.rne(1)
+    want = (s.full_m() - np.diag(m.dof_armature)) @ s.qacc + s.qfrc_bias
+    assert np.abs(full - want).max() < 1e-14
+
+
+def test_actuation_and_passive(cf_model):
+    m = cf_model
+    q, v = _random_state(m, 4)
+    s = OracleSim(m)
+    s.qpos[:] = q
+    s.qvel[:] = v
+    s.ctrl[:] = 10.0  # far outside ctrlrange -> clamped
+    s.forward()
+    j = m.actuator_trnid
+    want = np.clip(2.0 * np.clip(10.0, m.actuator_ctrlrange[:, 0], m.actuator_ctrlrange[:, 1]) - 2.0 * q[j], -1, 1)
+    assert np.abs(s.actuator_force - want).max() < 1e-15
+    assert np.abs(s.qfrc_actuator[j] - want).max() < 1e-15
+    assert np.abs(s.qfrc_passive + 0.1 * v).max() < 1e-16
+
+
+def test_constraint_rows_and_kkt(cf_model):
+    """Row order equality -> frictionloss -> limit; the Newton solution is the minimiser of
+    the convex cost: checked against scipy's L-BFGS from a different start and by gradient."""
+    from scipy.optimize import minimize
+    m = cf_model
+    s = OracleSim(m)
+    # default pose: 9 joints sit on a limit -> 4 + 21 + 9 rows
+    s.forward()
+    assert s.nefc == 34
+    t = s.efc("type")
+    assert t.tolist() == [0] * 4 + [1] * 21 + [3] * 9
+    q, v = _random_state(m, 8)
+    s.qpos[:] = q
+    s.qvel[:] = 0.3 * v
+    s.forward()
+    qa = s.qacc.copy()
+    c0 = s.cost(qa)
+    rng = np.random.default_rng(0)
+    scale = np.abs(qa).max()
+    for _ in range(20):
+        assert s.cost(qa + 1e-4 * scale * rng.normal(size=m.nv)) >= c0 - 1e-9 * abs(c0)
+    # gradient at the solution: M a - qfrc_smooth - J^T f = 0
+    J, f = s.efc("J"), s.efc("force")
+    g = s.full_m() @ qa - s.qfrc_smooth - J.T @ f
+    assert np.abs(g).max() * (1.0 / (m.stat_meaninertia * m.nv)) < 1e-6
+    assert np.abs(J.T @ f - s.qfrc_constraint).max() < 1e-12
+    res = minimize(lambda a: s.cost(a), s.qacc_smooth.copy(), method="L-BFGS-B",
+                   options=dict(maxiter=5000, ftol=1e-15, gtol=1e-12))
+    assert s.cost(res.x) >= c0 - 1e-7 * max(1.0, abs(c0))
+
+
+def test_limit_closed_form_single_dof(tmp_path):
+    """1-DOF limit hit: the solver's acceleration equals the closed-form minimiser."""
+    import mujoco_amd
+    xml = """<mujoco><compiler angle="radian"/><option gravity="0 0 0"><flag contact="disable"/></option>
+    <worldbody><body name="a"><joint name="j" axis="0 1 0" limited="true" range="-0.5 0.5" margin="0.01"/>
+    <geom type="sphere" size="0.1" pos="0 0 0.3"/></body></worldbody></mujoco>"""
+    m = mujoco_amd.load_model_from_xml(xml)
+    s = OracleSim(m)
+    s.qpos[0] = 0.52
+    s.qvel[0] = 0.1
+    s.forward()
+    assert s.nefc == 1
+    D, aref, J = s.efc("D")[0], s.efc("aref")[0], s.efc("J")[0, 0]
+    M = s.full_m()[0, 0]
+    a_s = s.qacc_smooth[0]
+    # minimise 0.5 M (a-a_s)^2 + 0.5 D (J a - aref)^2  (active since J a - aref < 0)
+    a = (M * a_s + D * J * aref) / (M + D * J * J)
+    assert J * a - aref < 0
+    assert abs(s.qacc[0] - a) < 1e-9 * abs(a)
+
+
+def test_energy_drift_contact_free(tmp_path):
+    """No damping/friction/limits/actuators: RK4 conserves energy to O(h^4); Euler drifts O(h)."""
+    import mujoco_amd
+    xml = """<mujoco><compiler angle="radian"/><option timestep="0.001" integrator="{I}"><flag contact="disable"/></option>
+    <worldbody><body name="a" pos="0 0 1"><joint name="j1" axis="0 1 0"/><geom type="capsule" size="0.02 0.2" pos="0 0 -0.2"/>
+      <body name="b" pos="0 0 -0.4"><joint name="j2" axis="0 1 0"/><geom type="capsule" size="0.02 0.15" pos="0 0 -0.15"/></body>
+    </body></worldbody></mujoco>"""
+
+    def energy(m, s):
+        s.forward()
+        T = 0.5 * s.qvel @ s.full_m() @ s.qvel
+        V = -sum(m.body_mass[b] * m.opt_gravity @ s.xipos[b] for b in range(1, m.nbody))
+        return T + V
+
+    drift = {}
+    for integ in ("RK4", "Euler"):
+        m = mujoco_amd.load_model_from_xml(xml.replace("{I}", integ))
+        s = OracleSim(m)
+        s.qpos[:] = [1.0, 0.5]
+        e0 = energy(m, s)
+        s.step(2000)
+        drift[integ] = abs(energy(m, s) - e0) / abs(e0)
+    assert drift["RK4"] < 1e-8
+    assert drift["Euler"] < 5e-2 and drift["Euler"] > drift["RK4"]
+
+
+def test_rk4_convergence_order():
+    """Smooth double pendulum (no clamps, no constraints): halving h cuts the error >= 12x."""
+    import mujoco_amd
+    xml = """<mujoco><compiler angle="radian"/><option timestep="{H}" integrator="RK4"><flag contact="disable"/></option>
+    <worldbody><body name="a" pos="0 0 1"><joint name="j1" axis="0 1 0" damping="0.01"/><geom type="capsule" size="0.02 0.2" pos="0 0 -0.2"/>
+      <body name="b" pos="0 0 -0.4"><joint name="j2" axis="0 1 0"/><geom type="capsule" size="0.02 0.15" pos="0 0 -0.15"/></body>
+    </body></worldbody></mujoco>"""
+    sols = []
+    for h, n in ((0.02, 25), (0.01, 50), (0.00125, 400)):
+        s = OracleSim(mujoco_amd.load_model_from_xml(xml.replace("{H}", repr(h))))
+        s.qpos[:] = [1.0, 0.5]
+        s.step(n)
+        sols.append(s.qpos.copy())
+    e1 = np.abs(sols[0] - sols[2]).max()
+    e2 = np.abs(sols[1] - sols[2]).max()
+    assert e2 < e1 / 12 and e1 > 1e-9
+
+
+def test_committed_trajectory_fixture(cf_model):
+    g = np.load(os.path.join(GOLDEN, "dexterous_oracle_traj.npz"))
+    s = OracleSim(cf_model)
+    for k in range(10):
+        s.step(100)
+        assert np.abs(s.qpos - g["qpos"][k]).max() < 1e-12
+        assert np.abs(s.qvel - g["qvel"][k]).max() < 1e-11
+
+
+def test_nan_guard_resets(cf_model):
+    s = OracleSim(cf_model)
+    s.qpos[2] = np.nan
+    s.step()
+    assert s.warning & 1 and np.isfinite(s.qpos).all()
