@@ -6,7 +6,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libbatchsim.so")
+LIB_PATH = os.environ.get("BS_LIB") or os.path.join(_HERE, "csrc", "libbatchsim.so")
 
 _I, _D = C.c_int32, C.c_double
 _IP, _DP = C.POINTER(C.c_int32), C.POINTER(C.c_double)

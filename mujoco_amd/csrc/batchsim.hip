@@ -12,6 +12,8 @@
 #include <vector>
 
 #include "physics_dev.h"
+#include "physics_tp.h"
+#include <cstdlib>
 
 // ------------------------------------------------------------------ errors
 static thread_local std::string g_err;
@@ -55,6 +57,7 @@ struct DeviceImage {
   int device = -1;
   void* blob = nullptr;
   DevModel dm;
+  TpModel tp;
 };
 
 struct bs_model {
@@ -65,8 +68,96 @@ struct bs_model {
   std::vector<int32_t> eq_dof1, eq_dof2, eq_jnt1, eq_jnt2, eq_Hadr, fric_dof, lim_jnt;
   std::vector<double> eq_data, eq_solref, eq_solimp;
   int damped = 0, hess_sparse = 1;
+  // tree-parallel kernel (physics_tp.h): per-lane table and eligibility
+  int tp_ok = 0;
+  std::string tp_why;
+  std::vector<int32_t> tp_table;  // [TPI_TOTAL][32]
+  TpModel tp;
   std::vector<DeviceImage> images;
 };
+
+// Decide whether the tree-parallel kernel can run this model and build its lane table.
+static void build_tp(bs_model* m) {
+  const bs_model_desc& s = m->d;
+  const int nb = s.nbody, nv = s.nv, nu = s.nu;
+  m->tp_ok = 0;
+  memset(&m->tp, 0, sizeof m->tp);
+  auto no = [&](const char* why) { m->tp_why = why; };
+  if (nb > TP_LPE) return no("more than 32 bodies");
+  std::vector<int> depth(nb, 0), dd(nv, 1), jnt_of(nb, -1), act_of(nv, -1);
+  for (int b = 1; b < nb; b++) {
+    depth[b] = depth[s.body_parentid[b]] + 1;
+    if (s.body_jntnum[b] > 1) return no("a body has more than one joint");
+    if (s.body_jntnum[b] == 1) jnt_of[b] = s.body_jntadr[b];
+  }
+  int maxdepth = 0, maxdd = 1;
+  for (int b = 0; b < nb; b++) maxdepth = depth[b] > maxdepth ? depth[b] : maxdepth;
+  for (int i = 0; i < nv; i++) {
+    dd[i] = s.dof_parentid[i] >= 0 ? dd[s.dof_parentid[i]] + 1 : 1;
+    maxdd = dd[i] > maxdd ? dd[i] : maxdd;
+  }
+  if (maxdd > TP_MAXD) return no("dof tree deeper than TP_MAXD");
+  if (maxdepth > 32) return no("body tree too deep");
+  for (int u = 0; u < nu; u++) {
+    if (act_of[s.actuator_trnid[u]] >= 0) return no("two actuators on one joint");
+    act_of[s.actuator_trnid[u]] = u;
+  }
+  std::vector<int32_t>& T = m->tp_table;
+  T.assign((size_t)TPI_TOTAL * TP_LPE, -1);
+  auto at = [&](int f, int l) -> int32_t& { return T[(size_t)f * TP_LPE + l]; };
+  for (int l = 0; l < TP_LPE; l++) {
+    at(TPI_PARENT, l) = l; at(TPI_DEPTH, l) = -1; at(TPI_DD, l) = 0; at(TPI_ROOT, l) = -1;
+  }
+  std::vector<int> nbc(nb, 0), ndc(nb, 0);
+  int nroots = 0;
+  for (int b = 0; b < nb; b++) {
+    at(TPI_PARENT, b) = b == 0 ? 0 : s.body_parentid[b];
+    at(TPI_DEPTH, b) = depth[b];
+    at(TPI_ROOT, b) = s.body_rootid[b];
+    if (b > 0 && s.body_parentid[b] == 0) {
+      if (nroots >= 4) return no("more than 4 kinematic trees");
+      m->tp.roots[nroots++] = b;
+    }
+    const int p = s.body_parentid[b];
+    if (b > 0 && p > 0) {
+      if (nbc[p] >= TP_MAXC) return no("a body has more than 8 children");
+      at(TPI_BCHILD + nbc[p]++, p) = b;
+      if (nbc[p] > m->tp.lvl_bchild[depth[b]]) m->tp.lvl_bchild[depth[b]] = nbc[p];
+    }
+    const int j = jnt_of[b];
+    if (j >= 0) {
+      at(TPI_JNT, b) = j;
+      at(TPI_DD, b) = dd[j];
+      at(TPI_ACT, b) = act_of[j];
+      int a = 1;
+      for (int k = s.dof_parentid[j]; k >= 0; k = s.dof_parentid[k], a++) at(TPI_ANC + a, b) = s.dof_bodyid[k];
+      const int pj = s.dof_parentid[j];
+      if (pj >= 0) {
+        const int pb = s.dof_bodyid[pj];
+        if (ndc[pb] >= TP_MAXC) return no("a dof has more than 8 child dofs");
+        at(TPI_DCHILD + ndc[pb]++, pb) = b;
+        if (ndc[pb] > m->tp.lvl_dchild[dd[j]]) m->tp.lvl_dchild[dd[j]] = ndc[pb];
+      }
+    }
+  }
+  // equalities: owner = dof1's lane, other = dof2 (must be an ancestor dof of dof1)
+  for (size_t r = 0; r < m->eq_dof1.size(); r++) {
+    const int d1 = m->eq_dof1[r], d2 = m->eq_dof2[r];
+    if (d2 < 0) return no("single-joint equality");
+    const int b1 = s.dof_bodyid[d1], b2 = s.dof_bodyid[d2];
+    int pos = -1, a = 1;
+    for (int k = s.dof_parentid[d1]; k >= 0; k = s.dof_parentid[k], a++)
+      if (k == d2) pos = a;
+    if (pos < 0) return no("equality joint2 is not an ancestor of joint1");
+    if (at(TPI_EQ_OWN, b1) >= 0 || at(TPI_EQ_SRC, b2) >= 0) return no("a dof takes part in two equalities of the same role");
+    at(TPI_EQ_OWN, b1) = (int)r; at(TPI_EQ_OTHER, b1) = b2; at(TPI_EQ_POS, b1) = pos; at(TPI_EQ_SRC, b2) = b1;
+  }
+  const int neq = (int)m->eq_dof1.size(), nfric = (int)m->fric_dof.size();
+  for (int k = 0; k < nfric; k++) at(TPI_FRIC_ROW, s.dof_bodyid[m->fric_dof[k]]) = neq + k;
+  for (size_t k = 0; k < m->lim_jnt.size(); k++) at(TPI_LIM_ROW, s.jnt_bodyid[m->lim_jnt[k]]) = neq + nfric + 2 * (int)k;
+  m->tp.maxdepth = maxdepth; m->tp.maxdd = maxdd; m->tp.nroots = nroots;
+  m->tp_ok = 1;
+}
 
 namespace {
 struct Packer {
@@ -234,6 +325,7 @@ extern "C" int bs_model_create(const bs_model_desc* desc, bs_model** out) {
     for (int j = 0; j < nj; j++)
       if (m->d.jnt_limited[j]) m->lim_jnt.push_back(j);
   for (int i = 0; i < nv; i++) m->damped |= m->d.dof_damping[i] > 0;
+  build_tp(m);
   *out = m;
   return BS_OK;
 }
@@ -255,9 +347,9 @@ extern "C" int bs_model_destroy(bs_model* m) {
 }
 
 // upload (once per device) and return the device-side view
-static int model_image(bs_model* m, int device, const DevModel** out) {
+static int model_image(bs_model* m, int device, const DeviceImage** out) {
   for (auto& im : m->images)
-    if (im.device == device) { *out = &im.dm; return BS_OK; }
+    if (im.device == device) { *out = &im; return BS_OK; }
   Packer pk;
   const bs_model_desc& s = m->d;
   const int nb = s.nbody, nj = s.njnt, nv = s.nv, nu = s.nu, ng = s.ngeom;
@@ -305,6 +397,9 @@ static int model_image(bs_model* m, int device, const DevModel** out) {
   PUT_D(eq_data, m->eq_data.data(), dm.neq * 5); PUT_D(eq_solref, m->eq_solref.data(), dm.neq * 2);
   PUT_D(eq_solimp, m->eq_solimp.data(), dm.neq * 5);
   PUT_I(fric_dof, m->fric_dof.data(), dm.nfric); PUT_I(lim_jnt, m->lim_jnt.data(), dm.nlim);
+  TpModel tp = m->tp;
+  tp.lane = nullptr;
+  if (m->tp_ok) fix.push_back({pk.add(m->tp_table.data(), m->tp_table.size() * sizeof(int32_t)), (void**)&tp.lane});
 #undef PUT_I
 #undef PUT_D
   HIPCHK(hipSetDevice(device));
@@ -313,9 +408,9 @@ static int model_image(bs_model* m, int device, const DevModel** out) {
   HIPCHK(hipMemcpy(blob, pk.bytes.data(), pk.bytes.size(), hipMemcpyHostToDevice));
   for (auto& f : fix) *f.slot = (char*)blob + f.off;
   DeviceImage im;
-  im.device = device; im.blob = blob; im.dm = dm;
+  im.device = device; im.blob = blob; im.dm = dm; im.tp = tp;
   m->images.push_back(im);
-  *out = &m->images.back().dm;
+  *out = &m->images.back();
   return BS_OK;
 }
 
@@ -329,6 +424,8 @@ struct FieldInfo {
 struct bs_sim {
   bs_model* model = nullptr;
   DevModel dm;
+  TpModel tp;
+  bool use_tp = false;
   DevData dd;
   int device = 0;
   long n_envs = 0, E = 0;
@@ -349,6 +446,11 @@ __global__ __launch_bounds__(BS_BLOCK) void k_step(DevModel m, DevData d, int ns
   const long e = (long)blockIdx.x * BS_BLOCK + threadIdx.x;
   if (e >= d.n_envs) return;
   for (int s = 0; s < nsteps; s++) env_step(m, d, e);
+}
+// tree-parallel kernel: 2 environments per 64-lane block (physics_tp.h)
+__global__ __launch_bounds__(64) void k_tp(DevModel m, TpModel t, DevData d, int nsteps, int mode, int dump) {
+  __shared__ int tbl[TPI_TOTAL * 64];
+  tp_run(m, t, d, nsteps, mode, dump, tbl);
 }
 __global__ __launch_bounds__(BS_BLOCK) void k_forward(DevModel m, DevData d) {
   const long e = (long)blockIdx.x * BS_BLOCK + threadIdx.x;
@@ -409,6 +511,13 @@ __global__ __launch_bounds__(BS_BLOCK) void k_frames(DevModel m, DevData d, doub
 }
 
 static inline dim3 grid_for(const bs_sim* s) { return dim3((unsigned)((s->n_envs + BS_BLOCK - 1) / BS_BLOCK)); }
+static inline dim3 grid_tp(const bs_sim* s) { return dim3((unsigned)((s->n_envs + 1) / 2)); }
+static void launch_step(bs_sim* s, int n_steps) {
+  if (s->use_tp)
+    hipLaunchKernelGGL(k_tp, grid_tp(s), dim3(64), 0, s->stream, s->dm, s->tp, s->dd, n_steps, 0, 1);
+  else
+    hipLaunchKernelGGL(k_step, grid_for(s), dim3(BS_BLOCK), 0, s->stream, s->dm, s->dd, n_steps);
+}
 
 extern "C" int bs_sim_create(const bs_model* const* models, int n_models, const int32_t* env_model_id,
                              int64_t n_envs, int device, const bs_options* opt, bs_sim** out) {
@@ -428,12 +537,23 @@ extern "C" int bs_sim_create(const bs_model* const* models, int n_models, const 
   }
   if (device < 0 || device >= ndev) return fail(BS_ERR_INVALID, "bs_sim_create: device %d out of range [0,%d)", device, ndev);
   bs_model* model = const_cast<bs_model*>(models[0]);
-  const DevModel* dmp = nullptr;
-  int rc = model_image(model, device, &dmp);
+  if (!(model->d.disableflags & BS_DSBL_CONTACT) && model->d.npair > 0)
+    return fail(BS_ERR_UNSUPPORTED,
+                "bs_sim_create: the collision stage (A5/A6) is not on the device yet; this model has %d "
+                "candidate geom pairs - disable contacts (<flag contact=\"disable\"/>) to step it joint-space only",
+                model->d.npair);
+  const DeviceImage* img = nullptr;
+  int rc = model_image(model, device, &img);
   if (rc) return rc;
 
   bs_sim* s = new bs_sim();
-  s->model = model; s->dm = *dmp; s->device = device; s->n_envs = n_envs;
+  s->model = model; s->dm = img->dm; s->tp = img->tp; s->device = device; s->n_envs = n_envs;
+  const char* kv = getenv("BS_KERNEL");
+  s->use_tp = model->tp_ok && !(kv && strcmp(kv, "serial") == 0);
+  if (kv && strcmp(kv, "tp") == 0 && !model->tp_ok) {
+    delete s;
+    return fail(BS_ERR_UNSUPPORTED, "BS_KERNEL=tp but the model is not eligible: %s", model->tp_why.c_str());
+  }
   s->E = (n_envs + 63) / 64 * 64;
   const DevModel& m = s->dm;
   const long E = s->E;
@@ -528,7 +648,7 @@ extern "C" int bs_step(bs_sim* s, int n_steps) {
   if (n_steps < 0) return fail(BS_ERR_INVALID, "bs_step: n_steps must be >= 0 (got %d)", n_steps);
   if (n_steps == 0) return BS_OK;
   HIPCHK(hipSetDevice(s->device));
-  hipLaunchKernelGGL(k_step, grid_for(s), dim3(BS_BLOCK), 0, s->stream, s->dm, s->dd, n_steps);
+  launch_step(s, n_steps);
   HIPCHK(hipGetLastError());
   return BS_OK;
 }
@@ -536,7 +656,10 @@ extern "C" int bs_step(bs_sim* s, int n_steps) {
 extern "C" int bs_forward(bs_sim* s) {
   if (!s) return fail(BS_ERR_INVALID, "bs_forward: null sim");
   HIPCHK(hipSetDevice(s->device));
-  hipLaunchKernelGGL(k_forward, grid_for(s), dim3(BS_BLOCK), 0, s->stream, s->dm, s->dd);
+  if (s->use_tp)
+    hipLaunchKernelGGL(k_tp, grid_tp(s), dim3(64), 0, s->stream, s->dm, s->tp, s->dd, 1, 1, 2);
+  else
+    hipLaunchKernelGGL(k_forward, grid_for(s), dim3(BS_BLOCK), 0, s->stream, s->dm, s->dd);
   HIPCHK(hipGetLastError());
   return BS_OK;
 }
@@ -645,9 +768,7 @@ extern "C" int bs_timed_steps(bs_sim* s, int n_steps, double* elapsed_ms) {
   if (n_steps < 1) return fail(BS_ERR_INVALID, "bs_timed_steps: n_steps must be >= 1");
   HIPCHK(hipSetDevice(s->device));
   HIPCHK(hipEventRecord(s->ev[5], s->stream));
-  for (int k = 0; k < n_steps; k++) {
-    hipLaunchKernelGGL(k_step, grid_for(s), dim3(BS_BLOCK), 0, s->stream, s->dm, s->dd, 1);
-  }
+  for (int k = 0; k < n_steps; k++) launch_step(s, 1);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(s->ev[6], s->stream));
   HIPCHK(hipEventSynchronize(s->ev[6]));

@@ -1,0 +1,868 @@
+// physics_tp.h — tree-parallel step kernel for gfx950: ONE LANE PER BODY (and its joint/dof),
+// 32 lanes per environment, two environments per 64-wide wavefront.
+//
+// Every per-environment intermediate (poses, spatial inertias, the sparse mass-matrix row of a
+// dof, its L^T D L factor, constraint rows, solver vectors) lives in the registers of the lane
+// that owns the body/dof; lanes exchange parent/child/ancestor data with ds_bpermute, and
+// environment-wide sums use DPP row operations + one ds_swizzle, so a step touches HBM only for
+// the state it loads and the outputs it stores.  Tree recursions run level by level (depth <= 7
+// for the exported hands) instead of body by body.
+//
+// Eligibility (checked on the host, otherwise the serial kernel in physics_dev.h is used):
+// nbody <= 32, at most one hinge/slide joint per body, dof depth <= TP_MAXD, every joint
+// equality couples a dof (joint1) with one of its ancestors (joint2), a dof owns / is referenced
+// by at most one equality, at most one actuator per joint, contacts disabled.
+//
+// Stage semantics and reference citations are those of physics_dev.h.
+#pragma once
+#include "physics_dev.h"
+
+#define TP_LPE 32   // lanes per environment
+#define TP_MAXD 6   // max entries in a dof's mass-matrix row (itself + 5 ancestor dofs)
+#define TP_MAXC 8   // max children per body / dof
+#define TP_NPAIR ((TP_MAXD - 1) * TP_MAXD / 2)
+
+#ifndef TP_HELPER_ATTR
+#define TP_HELPER_ATTR __forceinline__
+#endif
+
+// per-lane integer table, [field][32]
+enum {
+  TPI_PARENT = 0, TPI_DEPTH, TPI_JNT, TPI_DD, TPI_ROOT, TPI_ACT, TPI_EQ_OWN, TPI_EQ_OTHER, TPI_EQ_POS,
+  TPI_EQ_SRC, TPI_ANC,                       // TPI_ANC + a, a = 0..TP_MAXD-1 (a=0 unused)
+  TPI_BCHILD = TPI_ANC + TP_MAXD,            // + c
+  TPI_DCHILD = TPI_BCHILD + TP_MAXC,         // + c
+  TPI_COUNT = TPI_DCHILD + TP_MAXC,
+  TPI_FRIC_ROW = TPI_COUNT, TPI_LIM_ROW, TPI_TOTAL
+};
+
+struct TpModel {
+  const int* lane;  // [TPI_TOTAL][32]
+  int maxdepth, maxdd, nroots;
+  int roots[4];
+  int lvl_bchild[34];          // max #children over bodies at depth L-1, indexed by child depth L
+  int lvl_dchild[TP_MAXD + 2]; // max #dof-children over dofs with dd == D-1, indexed by D
+};
+
+// ---- cross-lane primitives.  `sa` arguments are ds_bpermute byte addresses (lane * 4).
+__device__ __forceinline__ double bperm(double v, int sa) {
+  const int lo = __builtin_amdgcn_ds_bpermute(sa, __double2loint(v));
+  const int hi = __builtin_amdgcn_ds_bpermute(sa, __double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double swz16(double v) {  // lane ^ 16 inside each 32-lane half
+  const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(v), 0x401F);
+  const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(v), 0x401F);
+  return __hiloint2double(hi, lo);
+}
+// all-reduce over the 32 lanes of an environment; every lane gets the bitwise-same sum
+__device__ __forceinline__ double env_sum(double v) {
+  v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_mov<0x141>(v);  // row_half_mirror
+  v += dpp_mov<0x140>(v);  // row_mirror
+  v += swz16(v);
+  return v;
+}
+__device__ __forceinline__ int env_sum_i(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false);
+  v += __builtin_amdgcn_ds_swizzle(v, 0x401F);
+  return v;
+}
+__device__ __forceinline__ bool env_any(bool p, int base) {
+  const unsigned long long b = __ballot(p);
+  return ((b >> base) & 0xffffffffull) != 0;
+}
+__device__ __forceinline__ constexpr int pair_idx(int a, int b) {  // 1 <= a <= b <= TP_MAXD-1
+  return (a - 1) * (TP_MAXD - 1) - (a - 1) * (a - 2) / 2 + (b - a);
+}
+
+typedef const int __attribute__((address_space(3))) * tp_lds_ptr;  // lane table in LDS
+struct TpRow { double r[TP_MAXD]; };
+struct TpFac { TpRow R; double dinv; };
+
+// what the dof-tree helpers need about this lane (passed by value, lives in registers)
+struct TpCtx {
+  int self_sa;           // own bpermute address
+  int anc_sa[TP_MAXD];   // address of the a-th ancestor dof's lane (own address if none)
+  int dd;                // entries in this dof's row (0 = no dof on this lane)
+  int maxdd;
+  int nchild[TP_MAXD + 2];  // lvl_dchild
+  tp_lds_ptr tbl;        // LDS table
+};
+
+// sparse L^T D L of the distributed rows (mj_factorM layout): R[0] diagonal, R[a] the entry with
+// the a-th ancestor dof.  Level by level from the leaves: a finished dof sends the outer-product
+// packet T(a,b) = L(k,a) M(k,b) + (packets forwarded from below) to its parent, which applies the
+// (1,b) entries to its own row and forwards the rest one position up.
+__device__ TP_HELPER_ATTR TpFac tp_factor(TpCtx c, TpRow Rin) {
+  double* R = Rin.r;
+  double A[TP_NPAIR];
+#pragma unroll
+  for (int k = 0; k < TP_NPAIR; k++) A[k] = 0;
+  double dinv = 1.0;
+#pragma unroll
+  for (int D = TP_MAXD; D >= 1; D--) {
+    if (D > c.maxdd) continue;
+    const bool is = c.dd == D;
+    double T[TP_NPAIR];
+    const double r0 = is ? R[0] : 1.0;
+    const double ir0 = 1.0 / r0;
+#pragma unroll
+    for (int a = 1; a < TP_MAXD; a++) {
+      if (a >= D) continue;
+      const double tmp = R[a] * ir0;
+#pragma unroll
+      for (int b = a; b < TP_MAXD; b++) {
+        if (b >= D) continue;
+        T[pair_idx(a, b)] = is ? tmp * R[b] + A[pair_idx(a, b)] : 0.0;
+      }
+      if (is) R[a] = tmp;
+    }
+    if (is) dinv = ir0;
+    if (D == 1) break;
+    const bool par = c.dd == D - 1;
+    for (int ch = 0; ch < c.nchild[D]; ch++) {
+      const int src = c.tbl[(TPI_DCHILD + ch) * 64 + threadIdx.x];
+      const bool take = par && src >= 0;
+      const int sa = src >= 0 ? src : c.self_sa;
+#pragma unroll
+      for (int a = 1; a < TP_MAXD; a++) {
+        if (a >= D) continue;
+#pragma unroll
+        for (int b = a; b < TP_MAXD; b++) {
+          if (b >= D) continue;
+          const double v = bperm(T[pair_idx(a, b)], sa);
+          if (take) {
+            if (a == 1) R[b - 1] -= v;
+            else A[pair_idx(a - 1, b - 1)] += v;
+          }
+        }
+      }
+    }
+  }
+  TpFac out;
+#pragma unroll
+  for (int a = 0; a < TP_MAXD; a++) out.R.r[a] = R[a];
+  out.dinv = dinv;
+  return out;
+}
+
+// x <- (L^T D L)^-1 x (mj_solveM): leaves-to-root sweep, diagonal scale, root-to-leaves sweep
+__device__ TP_HELPER_ATTR double tp_solve(TpCtx c, TpRow Rin, double dinv, double x) {
+  const double* R = Rin.r;
+  double W[TP_MAXD];
+#pragma unroll
+  for (int a = 0; a < TP_MAXD; a++) W[a] = 0;
+#pragma unroll
+  for (int D = TP_MAXD; D >= 2; D--) {
+    if (D > c.maxdd) continue;
+    const bool is = c.dd == D, par = c.dd == D - 1;
+    double T[TP_MAXD];
+#pragma unroll
+    for (int a = 1; a < TP_MAXD; a++)
+      if (a < D) T[a] = is ? R[a] * x + W[a] : 0.0;
+    for (int ch = 0; ch < c.nchild[D]; ch++) {
+      const int src = c.tbl[(TPI_DCHILD + ch) * 64 + threadIdx.x];
+      const bool take = par && src >= 0;
+      const int sa = src >= 0 ? src : c.self_sa;
+#pragma unroll
+      for (int a = 1; a < TP_MAXD; a++) {
+        if (a >= D) continue;
+        const double v = bperm(T[a], sa);
+        if (take) {
+          if (a == 1) x -= v;
+          else W[a - 1] += v;
+        }
+      }
+    }
+  }
+  x *= dinv;
+#pragma unroll
+  for (int D = 2; D <= TP_MAXD; D++) {
+    if (D > c.maxdd) continue;
+    const bool is = c.dd == D;
+#pragma unroll
+    for (int a = 1; a < TP_MAXD; a++) {
+      if (a >= D) continue;
+      const double xa = bperm(x, c.anc_sa[a]);
+      if (is) x -= R[a] * xa;
+    }
+  }
+  return x;
+}
+
+// res = M v with the distributed sparse rows (mj_mulM)
+__device__ TP_HELPER_ATTR double tp_mul_m(TpCtx c, TpRow Min, double v) {
+  const double* Mr = Min.r;
+  double res = c.dd > 0 ? Mr[0] * v : 0.0;
+#pragma unroll
+  for (int a = 1; a < TP_MAXD; a++) {
+    if (a >= c.maxdd) continue;
+    const double va = bperm(v, c.anc_sa[a]);
+    if (a < c.dd) res += Mr[a] * va;
+  }
+  double W[TP_MAXD];
+#pragma unroll
+  for (int a = 0; a < TP_MAXD; a++) W[a] = 0;
+#pragma unroll
+  for (int D = TP_MAXD; D >= 2; D--) {
+    if (D > c.maxdd) continue;
+    const bool is = c.dd == D, par = c.dd == D - 1;
+    double T[TP_MAXD];
+#pragma unroll
+    for (int a = 1; a < TP_MAXD; a++)
+      if (a < D) T[a] = is ? Mr[a] * v + W[a] : 0.0;
+    for (int ch = 0; ch < c.nchild[D]; ch++) {
+      const int src = c.tbl[(TPI_DCHILD + ch) * 64 + threadIdx.x];
+      const bool take = par && src >= 0;
+      const int sa = src >= 0 ? src : c.self_sa;
+#pragma unroll
+      for (int a = 1; a < TP_MAXD; a++) {
+        if (a >= D) continue;
+        const double x = bperm(T[a], sa);
+        if (take) {
+          if (a == 1) res += x;
+          else W[a - 1] += x;
+        }
+      }
+    }
+  }
+  return res;
+}
+
+// per-lane constraint rows (fixed layout: friction row, two limit rows, one owned equality row)
+struct TpRows {
+  double Df, rf, aref_f, fl;     // dof friction loss
+  double Dl0, Dl1, aref_l0, aref_l1;  // lower / upper joint limit (D = 0 when inactive)
+  double De, aref_e, ce;         // owned equality: J = e_own - ce * e_other
+  double De_o, ce_o;             // equality in which this dof is the 'other' one (from its owner)
+  bool own;                      // owns an equality row
+};
+
+struct TpSol {
+  double qacc, Ma, grad, search, Mv;
+  double jf, jl0, jl1, je;      // residuals J*qacc - aref
+  double vf, vl0, vl1, ve;      // J*search
+};
+
+// impedance with the common power == 2 case evaluated without pow()
+__device__ __forceinline__ double tp_impedance(const double* solimp, double pos, double margin) {
+  const double dmin = fmin(fmax(solimp[0], BS_MINIMP), BS_MAXIMP), dmax = fmin(fmax(solimp[1], BS_MINIMP), BS_MAXIMP);
+  const double width = fmax(solimp[2], BS_MINVAL), mid = fmin(fmax(solimp[3], BS_MINIMP), BS_MAXIMP);
+  const double power = fmax(solimp[4], 1.0);
+  const double x = fabs(pos - margin) / width;
+  if (dmin == dmax || x >= 1.0) return (x >= 1.0) ? dmax : 0.5 * (dmin + dmax);
+  if (x <= 0) return dmin;
+  double y;
+  if (power == 1.0) y = x;
+  else if (power == 2.0) y = (x <= mid) ? x * x / mid : 1 - (1 - x) * (1 - x) / (1 - mid);
+  else if (x <= mid) y = pow(x, power) / pow(mid, power - 1);
+  else y = 1 - pow(1 - x, power) / pow(1 - mid, power - 1);
+  return dmin + y * (dmax - dmin);
+}
+
+// cost of this lane's rows at its residuals; optional forces f = {friction, lower, upper, equality}
+template <bool FORCE>
+__device__ __forceinline__ double tp_rows_cost(const TpRows& r, double jf, double jl0, double jl1, double je,
+                                               double* f) {
+  double cost = 0, fe = 0, ff = 0, f0 = 0, f1 = 0;
+  if (r.own) { cost += 0.5 * r.De * je * je; fe = -r.De * je; }
+  if (r.Df > 0) {
+    if (jf <= -r.rf) { ff = r.fl; cost += -r.fl * (0.5 * r.rf + jf); }
+    else if (jf >= r.rf) { ff = -r.fl; cost += -r.fl * (0.5 * r.rf - jf); }
+    else { ff = -r.Df * jf; cost += 0.5 * r.Df * jf * jf; }
+  }
+  if (jl0 < 0) { f0 = -r.Dl0 * jl0; cost += 0.5 * r.Dl0 * jl0 * jl0; }
+  if (jl1 < 0) { f1 = -r.Dl1 * jl1; cost += 0.5 * r.Dl1 * jl1 * jl1; }
+  if (FORCE) { f[0] = ff; f[1] = f0; f[2] = f1; f[3] = fe; }
+  return cost;
+}
+
+struct TpLs { double alpha, cost, d0, d1; };
+
+__device__ TP_HELPER_ATTR TpLs tp_ls_eval(TpRows r, TpSol s, double alpha, double g0, double g1, double g2) {
+  double q0 = 0, q1 = 0, q2 = 0;
+  if (r.own) {
+    const double x = s.je + alpha * s.ve;
+    q0 += 0.5 * r.De * x * x; q1 += r.De * x * s.ve; q2 += 0.5 * r.De * s.ve * s.ve;
+  }
+  if (r.Df > 0) {
+    const double x = s.jf + alpha * s.vf;
+    if (x <= -r.rf) { q0 += -r.fl * (0.5 * r.rf + x); q1 += -r.fl * s.vf; }
+    else if (x >= r.rf) { q0 += -r.fl * (0.5 * r.rf - x); q1 += r.fl * s.vf; }
+    else { q0 += 0.5 * r.Df * x * x; q1 += r.Df * x * s.vf; q2 += 0.5 * r.Df * s.vf * s.vf; }
+  }
+  {
+    const double x = s.jl0 + alpha * s.vl0;
+    if (x < 0) { q0 += 0.5 * r.Dl0 * x * x; q1 += r.Dl0 * x * s.vl0; q2 += 0.5 * r.Dl0 * s.vl0 * s.vl0; }
+  }
+  {
+    const double x = s.jl1 + alpha * s.vl1;
+    if (x < 0) { q0 += 0.5 * r.Dl1 * x * x; q1 += r.Dl1 * x * s.vl1; q2 += 0.5 * r.Dl1 * s.vl1 * s.vl1; }
+  }
+  q0 = env_sum(q0); q1 = env_sum(q1); q2 = env_sum(q2);
+  TpLs p;
+  p.alpha = alpha;
+  p.cost = g0 + q0 + alpha * g1 + alpha * alpha * g2;
+  p.d0 = g1 + q1 + 2 * alpha * g2;
+  p.d1 = 2 * (g2 + q2);
+  if (p.d1 <= 0) p.d1 = BS_MINVAL;
+  return p;
+}
+
+// exact line search (same shape as physics_dev.h::line_search); all values are env-uniform
+__device__ __forceinline__ double tp_line_search(const DevModel& m, const TpRows& r, const TpSol& s,
+                                                 double gauss, double scale, double qfrc_smooth) {
+  const double snorm = sqrt(env_sum(s.search * s.search));
+  if (snorm < BS_MINVAL) return 0;
+  const double gtol = m.tolerance * m.ls_tolerance * snorm / scale;
+  const double g1 = env_sum(s.search * (s.Ma - qfrc_smooth));
+  const double g2 = 0.5 * env_sum(s.search * s.Mv);
+  int it = 0;
+  const int maxit = m.ls_iterations;
+  const TpLs p0 = tp_ls_eval(r, s, 0.0, gauss, g1, g2);
+  TpLs p1 = tp_ls_eval(r, s, p0.alpha - p0.d0 / p0.d1, gauss, g1, g2);
+  if (p0.cost < p1.cost) p1 = p0;
+  if (fabs(p1.d0) < gtol) return p1.alpha;
+  const double dir = p1.d0 < 0 ? 1.0 : -1.0;
+  bool p2update = false;
+  TpLs p2 = p1;
+  while (p1.d0 * dir <= -gtol && it < maxit) {
+    p2 = p1; p2update = true;
+    p1 = tp_ls_eval(r, s, p1.alpha - p1.d0 / p1.d1, gauss, g1, g2);
+    it++;
+    if (fabs(p1.d0) < gtol) return p1.alpha;
+  }
+  if (it >= maxit || !p2update) return p1.alpha;
+  TpLs p2next = p1;
+  TpLs p1next = tp_ls_eval(r, s, p1.alpha - p1.d0 / p1.d1, gauss, g1, g2);
+  while (it < maxit) {
+    const TpLs pmid = tp_ls_eval(r, s, 0.5 * (p1.alpha + p2.alpha), gauss, g1, g2);
+    it++;
+    bool b1 = false, b2 = false;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const TpLs c = k == 0 ? p1next : (k == 1 ? p2next : pmid);
+      if (fabs(c.d0) < gtol) return c.alpha;
+      if (c.d0 * dir < 0) {
+        if (c.alpha * dir > p2.alpha * dir && c.alpha * dir < p1.alpha * dir) { p2 = c; b2 = true; }
+      } else {
+        if (c.alpha * dir < p1.alpha * dir && c.alpha * dir > p2.alpha * dir) { p1 = c; b1 = true; }
+      }
+    }
+    if (!b1 && !b2) break;
+    if (b1) p1next = tp_ls_eval(r, s, p1.alpha - p1.d0 / p1.d1, gauss, g1, g2);
+    if (b2) p2next = tp_ls_eval(r, s, p2.alpha - p2.d0 / p2.d1, gauss, g1, g2);
+  }
+  const TpLs best = p1.cost <= p2.cost ? p1 : p2;
+  return best.cost < p0.cost ? best.alpha : 0.0;
+}
+
+// ------------------------------------------------------------------ kernel body
+// mode 0: nsteps x mj_step; mode 1: one mj_forward.  dump 0: state only, 1: + poses and
+// generalized forces of the last forward pass, 2: every intermediate the parity tests read.
+__device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, const DevData& d, int nsteps,
+                                       int mode, int dump, int* tbl) {
+  const int tid = threadIdx.x;
+  const int l = tid & (TP_LPE - 1), base = tid & ~(TP_LPE - 1);
+  // lane table -> LDS; lane references become ds_bpermute byte addresses
+  for (int f = 0; f < TPI_TOTAL; f++) {
+    int v = t.lane[f * TP_LPE + l];
+    const bool is_lane = f == TPI_PARENT || f == TPI_EQ_OTHER || f == TPI_EQ_SRC ||
+                         (f >= TPI_ANC && f < TPI_COUNT);
+    if (is_lane && v >= 0) v = (base + v) * 4;
+    tbl[f * 64 + tid] = v;
+  }
+  __syncthreads();
+  long env = (long)blockIdx.x * (64 / TP_LPE) + (tid / TP_LPE);
+  const bool env_ok = env < d.n_envs;
+  if (!env_ok) env = d.n_envs - 1;
+  const long E = d.E, e = env;
+  const int self_sa = tid * 4;
+  const int par_sa = tbl[TPI_PARENT * 64 + tid];
+  const int depth = tbl[TPI_DEPTH * 64 + tid], jnt = tbl[TPI_JNT * 64 + tid];
+  const int root = tbl[TPI_ROOT * 64 + tid], act = tbl[TPI_ACT * 64 + tid];
+  const int eq_own = tbl[TPI_EQ_OWN * 64 + tid], eq_pos = tbl[TPI_EQ_POS * 64 + tid];
+  const int eq_other_raw = tbl[TPI_EQ_OTHER * 64 + tid], eq_src_raw = tbl[TPI_EQ_SRC * 64 + tid];
+  const int eq_other_sa = eq_other_raw >= 0 ? eq_other_raw : self_sa;
+  const int eq_src_sa = eq_src_raw >= 0 ? eq_src_raw : self_sa;
+  const bool has_dof = jnt >= 0, is_src = eq_src_raw >= 0;
+  const bool isb = l < m.nbody && l > 0;
+  const int b = l < m.nbody ? l : 0, j = has_dof ? jnt : 0;
+  TpCtx c;
+  c.self_sa = self_sa; c.dd = has_dof ? tbl[TPI_DD * 64 + tid] : 0; c.maxdd = t.maxdd; c.tbl = (tp_lds_ptr)tbl;
+#pragma unroll
+  for (int a = 0; a < TP_MAXD; a++) {
+    const int v = tbl[(TPI_ANC + a) * 64 + tid];
+    c.anc_sa[a] = v >= 0 ? v : self_sa;
+  }
+#pragma unroll
+  for (int D = 0; D < TP_MAXD + 2; D++) c.nchild[D] = t.lvl_dchild[D];
+
+  // per-lane model constants
+  const V3 bpos = ld3(m.body_pos + 3 * b), jpos = ld3(m.jnt_pos + 3 * j), jax = ld3(m.jnt_axis + 3 * j);
+  const Q4 bquat = ld4(m.body_quat + 4 * b);
+  const int jtype = m.jnt_type[j];
+  const double mass = isb ? m.body_mass[b] : 0.0, qpos0 = m.qpos0[j];
+  const double damping = has_dof ? m.dof_damping[j] : 0.0;
+  const double h = m.timestep;
+  const double scale = 1.0 / (m.meaninertia * (m.nv > 1 ? m.nv : 1));
+
+  // state
+  double qpos = has_dof ? AT(d.qpos, j) : 0.0, qvel = has_dof ? AT(d.qvel, j) : 0.0;
+  double qfrc_applied = has_dof ? AT(d.qfrc_applied, j) : 0.0, qacc = has_dof ? AT(d.qacc, j) : 0.0;
+  double qacc_ws = has_dof ? AT(d.qacc_warmstart, j) : 0.0, ctrl = act >= 0 ? AT(d.ctrl, act) : 0.0;
+  double time = AT(d.time, 0);
+  int warning = AT(d.warning, 0), solver_iter = AT(d.solver_iter, 0), nefc = AT(d.nefc, 0);
+  bool was_reset = false;
+  auto reset_state = [&]() {
+    qpos = has_dof ? qpos0 : 0.0; qvel = 0; ctrl = 0; qfrc_applied = 0; qacc = 0; qacc_ws = 0; time = 0;
+    solver_iter = 0; nefc = 0; was_reset = true;
+  };
+
+  const int nstage = (mode == 0 && m.integrator == 1) ? 4 : 1;
+  for (int step = 0; step < nsteps; step++) {
+    if (mode == 0) {  // A14 mj_checkPos / mj_checkVel
+      if (env_any(has_dof && bad_num(qpos), base)) { reset_state(); warning |= 1; }
+      if (env_any(has_dof && bad_num(qvel), base)) { reset_state(); warning |= 2; }
+    }
+    double rk_q0 = qpos, rk_v0 = qvel, rk_t0 = time, rk_dq = 0, rk_dv = 0;
+    bool redone = false;
+    for (int stage = 0; stage < nstage; stage++) {
+      // ================= forward pass (single inlined site) =================
+      // ---- A1 kinematics: joint-local transform first (no parent needed), then one
+      // quaternion/vector compose per tree level
+      const double dq = qpos - qpos0;
+      Q4 lq = bquat;
+      V3 lp = bpos;
+      if (has_dof) {
+        if (jtype == BS_JNT_SLIDE) {
+          const V3 s = mrot(q2m(bquat), jax);
+          lp = {bpos.x + s.x * dq, bpos.y + s.y * dq, bpos.z + s.z * dq};
+        } else {
+          double sn, cs;
+          sincos(0.5 * dq, &sn, &cs);
+          const Q4 qj = {cs, jax.x * sn, jax.y * sn, jax.z * sn};
+          lq = qmul(bquat, qj);
+          const V3 rj = mrot(q2m(qj), jpos);
+          const V3 dl = mrot(q2m(bquat), V3{jpos.x - rj.x, jpos.y - rj.y, jpos.z - rj.z});
+          lp = {bpos.x + dl.x, bpos.y + dl.y, bpos.z + dl.z};
+        }
+      }
+      V3 pos = {0, 0, 0};
+      Q4 quat = {1, 0, 0, 0};
+      for (int lvl = 1; lvl <= t.maxdepth; lvl++) {
+        const V3 pp = {bperm(pos.x, par_sa), bperm(pos.y, par_sa), bperm(pos.z, par_sa)};
+        const Q4 pq = {bperm(quat.w, par_sa), bperm(quat.x, par_sa), bperm(quat.y, par_sa), bperm(quat.z, par_sa)};
+        if (isb && depth == lvl) {
+          const V3 tt = mrot(q2m(pq), lp);
+          pos = {pp.x + tt.x, pp.y + tt.y, pp.z + tt.z};
+          quat = qmul(pq, lq);
+          const double n2 = quat.w * quat.w + quat.x * quat.x + quat.y * quat.y + quat.z * quat.z;
+          const double inv = 1.0 / sqrt(n2);
+          quat.w *= inv; quat.x *= inv; quat.y *= inv; quat.z *= inv;
+        }
+      }
+      const M3 xmat = q2m(quat);
+      V3 axis = mrot(xmat, jax), anchor;
+      {
+        const V3 a = mrot(xmat, jpos);
+        anchor = {pos.x + a.x, pos.y + a.y, pos.z + a.z};
+        if (jtype == BS_JNT_SLIDE) { anchor.x -= axis.x * dq; anchor.y -= axis.y * dq; anchor.z -= axis.z * dq; }
+      }
+      // ---- A2 comPos
+      V3 xipos;
+      {
+        const V3 ip = mrot(xmat, ld3(m.body_ipos + 3 * b));
+        xipos = {pos.x + ip.x, pos.y + ip.y, pos.z + ip.z};
+      }
+      V3 com = {0, 0, 0};
+      for (int r = 0; r < t.nroots; r++) {
+        const int rb = t.roots[r];
+        const bool mine = isb && root == rb;
+        const double sx = env_sum(mine ? mass * xipos.x : 0.0), sy = env_sum(mine ? mass * xipos.y : 0.0),
+                     sz = env_sum(mine ? mass * xipos.z : 0.0);
+        const double sm = m.body_subtreemass[rb];
+        const int ra = (base + rb) * 4;
+        const double rx = bperm(xipos.x, ra), ry = bperm(xipos.y, ra), rz = bperm(xipos.z, ra);
+        if (mine) {
+          if (sm < BS_MINVAL) com = {rx, ry, rz};
+          else com = {sx / sm, sy / sm, sz / sm};
+        }
+      }
+      double cinert[10], cdof[6];
+      {
+        const M3 R = q2m(qmul(quat, ld4(m.body_iquat + 4 * b)));
+        const double* I = m.body_inertia + 3 * b;
+        const double off[3] = {xipos.x - com.x, xipos.y - com.y, xipos.z - com.z};
+        double tt[9];
+#pragma unroll
+        for (int rr = 0; rr < 3; rr++)
+#pragma unroll
+          for (int k = 0; k < 3; k++) tt[3 * rr + k] = R.a[3 * rr + k] * I[k];
+        cinert[0] = tt[0] * R.a[0] + tt[1] * R.a[1] + tt[2] * R.a[2];
+        cinert[1] = tt[3] * R.a[3] + tt[4] * R.a[4] + tt[5] * R.a[5];
+        cinert[2] = tt[6] * R.a[6] + tt[7] * R.a[7] + tt[8] * R.a[8];
+        cinert[3] = tt[0] * R.a[3] + tt[1] * R.a[4] + tt[2] * R.a[5];
+        cinert[4] = tt[0] * R.a[6] + tt[1] * R.a[7] + tt[2] * R.a[8];
+        cinert[5] = tt[3] * R.a[6] + tt[4] * R.a[7] + tt[5] * R.a[8];
+        cinert[0] += mass * (off[1] * off[1] + off[2] * off[2]);
+        cinert[1] += mass * (off[0] * off[0] + off[2] * off[2]);
+        cinert[2] += mass * (off[0] * off[0] + off[1] * off[1]);
+        cinert[3] -= mass * off[0] * off[1];
+        cinert[4] -= mass * off[0] * off[2];
+        cinert[5] -= mass * off[1] * off[2];
+        cinert[6] = mass * off[0]; cinert[7] = mass * off[1]; cinert[8] = mass * off[2]; cinert[9] = mass;
+        if (!isb)
+#pragma unroll
+          for (int k = 0; k < 10; k++) cinert[k] = 0;
+      }
+      if (has_dof && jtype == BS_JNT_SLIDE) {
+        cdof[0] = cdof[1] = cdof[2] = 0;
+        cdof[3] = axis.x; cdof[4] = axis.y; cdof[5] = axis.z;
+      } else if (has_dof) {
+        const V3 cc = cross(axis, V3{com.x - anchor.x, com.y - anchor.y, com.z - anchor.z});
+        cdof[0] = axis.x; cdof[1] = axis.y; cdof[2] = axis.z;
+        cdof[3] = cc.x; cdof[4] = cc.y; cdof[5] = cc.z;
+      } else {
+#pragma unroll
+        for (int k = 0; k < 6; k++) cdof[k] = 0;
+      }
+      // ---- A3 crb (children folded into parents, deepest level first) + mass-matrix rows
+      TpRow Mr;
+      {
+        double crb[10];
+#pragma unroll
+        for (int k = 0; k < 10; k++) crb[k] = cinert[k];
+        for (int lvl = t.maxdepth; lvl >= 2; lvl--) {
+          const bool par = isb && depth == lvl - 1;
+          for (int ch = 0; ch < t.lvl_bchild[lvl]; ch++) {
+            const int src = tbl[(TPI_BCHILD + ch) * 64 + tid];
+            const bool take = par && src >= 0;
+            const int sa = src >= 0 ? src : self_sa;
+#pragma unroll
+            for (int k = 0; k < 10; k++) {
+              const double v = bperm(crb[k], sa);
+              if (take) crb[k] += v;
+            }
+          }
+        }
+        double buf[6];
+        mul_inert_vec(buf, crb, cdof);
+        double s0 = 0;
+#pragma unroll
+        for (int k = 0; k < 6; k++) s0 += cdof[k] * buf[k];
+        Mr.r[0] = has_dof ? m.dof_armature[j] + s0 : 1.0;
+#pragma unroll
+        for (int a = 1; a < TP_MAXD; a++) {
+          Mr.r[a] = 0;
+          if (a >= t.maxdd) continue;
+          double sj = 0;
+#pragma unroll
+          for (int k = 0; k < 6; k++) sj += bperm(cdof[k], c.anc_sa[a]) * buf[k];
+          if (a < c.dd) Mr.r[a] = sj;
+        }
+      }
+      // ---- A4 factor M
+      const TpFac LM = tp_factor(c, Mr);
+      // ---- A8 comVel + rne bias
+      double cvel[6], qfrc_bias;
+      {
+        double acc[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < 6; k++) cvel[k] = 0;
+        if (l == 0 && !(m.disableflags & BS_DSBL_GRAVITY)) {
+          acc[3] = -m.gravity[0]; acc[4] = -m.gravity[1]; acc[5] = -m.gravity[2];
+        }
+        for (int lvl = 1; lvl <= t.maxdepth; lvl++) {
+          double pv[6], pa[6];
+#pragma unroll
+          for (int k = 0; k < 6; k++) { pv[k] = bperm(cvel[k], par_sa); pa[k] = bperm(acc[k], par_sa); }
+          if (isb && depth == lvl) {
+            double cdd[6];
+            cross_motion(cdd, pv, cdof);
+#pragma unroll
+            for (int k = 0; k < 6; k++) { acc[k] = pa[k] + cdd[k] * qvel; cvel[k] = pv[k] + cdof[k] * qvel; }
+          }
+        }
+        double t0[6], t1[6], t2[6], f[6];
+        mul_inert_vec(t0, cinert, acc);
+        mul_inert_vec(t1, cinert, cvel);
+        cross_force(t2, cvel, t1);
+#pragma unroll
+        for (int k = 0; k < 6; k++) f[k] = isb ? t0[k] + t2[k] : 0.0;
+        for (int lvl = t.maxdepth; lvl >= 2; lvl--) {
+          const bool par = isb && depth == lvl - 1;
+          for (int ch = 0; ch < t.lvl_bchild[lvl]; ch++) {
+            const int src = tbl[(TPI_BCHILD + ch) * 64 + tid];
+            const bool take = par && src >= 0;
+            const int sa = src >= 0 ? src : self_sa;
+#pragma unroll
+            for (int k = 0; k < 6; k++) {
+              const double x = bperm(f[k], sa);
+              if (take) f[k] += x;
+            }
+          }
+        }
+        double s = 0;
+#pragma unroll
+        for (int k = 0; k < 6; k++) s += cdof[k] * f[k];
+        qfrc_bias = s;
+      }
+      // ---- passive + A9 actuation + A10 smooth acceleration
+      double qfrc_passive = 0, act_force = 0, qfrc_actuator = 0;
+      if (has_dof && !(m.disableflags & BS_DSBL_PASSIVE))
+        qfrc_passive = -m.jnt_stiffness[j] * (qpos - m.qpos_spring[j]) - damping * qvel;
+      if (act >= 0 && !(m.disableflags & BS_DSBL_ACTUATION)) {
+        const double gear = m.actuator_gear[act];
+        double cc = ctrl;
+        if (m.actuator_ctrllimited[act] && !(m.disableflags & BS_DSBL_CLAMPCTRL)) {
+          cc = fmax(cc, m.actuator_ctrlrange[2 * act]);
+          cc = fmin(cc, m.actuator_ctrlrange[2 * act + 1]);
+        }
+        const double* bp = m.actuator_biasprm + 3 * act;
+        double f = m.actuator_gainprm[3 * act] * cc + bp[0] + bp[1] * (gear * qpos) + bp[2] * (gear * qvel);
+        if (m.actuator_forcelimited[act]) {
+          f = fmax(f, m.actuator_forcerange[2 * act]);
+          f = fmin(f, m.actuator_forcerange[2 * act + 1]);
+        }
+        act_force = f;
+        qfrc_actuator = gear * f;
+      }
+      const double qfrc_smooth = has_dof ? qfrc_passive - qfrc_bias + qfrc_applied + qfrc_actuator : 0.0;
+      const double qacc_smooth = tp_solve(c, LM.R, LM.dinv, qfrc_smooth);
+
+      // ---- A7 constraint rows
+      TpRows r;
+      r.Df = r.rf = r.aref_f = r.fl = 0; r.Dl0 = r.Dl1 = r.aref_l0 = r.aref_l1 = 0;
+      r.De = r.aref_e = r.ce = 0; r.De_o = r.ce_o = 0; r.own = false;
+      int nact = 0;
+      const bool con_on = !(m.disableflags & BS_DSBL_CONSTRAINT);
+      if (con_on && has_dof) {
+        const double iw = m.dof_invweight0[j];
+        if (!(m.disableflags & BS_DSBL_FRICTIONLOSS) && m.dof_frictionloss[j] > 0) {
+          double K, B;
+          const double imp = tp_impedance(m.dof_solimp + 5 * j, 0.0, 0.0);
+          kb_from_solref(m, m.dof_solref + 2 * j, m.dof_solimp + 5 * j, K, B);
+          const double R = fmax(BS_MINVAL, (1 - imp) * iw / imp);
+          r.Df = 1.0 / R; r.fl = m.dof_frictionloss[j]; r.rf = R * r.fl; r.aref_f = -B * qvel;
+          nact++;
+        }
+        if (!(m.disableflags & BS_DSBL_LIMIT) && m.jnt_limited[j]) {
+          const double margin = m.jnt_margin[j];
+          double K, B;
+          kb_from_solref(m, m.jnt_solref + 2 * j, m.jnt_solimp + 5 * j, K, B);
+          const double d0 = qpos - m.jnt_range[2 * j], d1 = m.jnt_range[2 * j + 1] - qpos;
+          if (d0 < margin) {
+            const double imp = tp_impedance(m.jnt_solimp + 5 * j, d0, margin);
+            r.Dl0 = 1.0 / fmax(BS_MINVAL, (1 - imp) * iw / imp);
+            r.aref_l0 = -B * qvel - K * imp * (d0 - margin);
+            nact++;
+          }
+          if (d1 < margin) {
+            const double imp = tp_impedance(m.jnt_solimp + 5 * j, d1, margin);
+            r.Dl1 = 1.0 / fmax(BS_MINVAL, (1 - imp) * iw / imp);
+            r.aref_l1 = B * qvel - K * imp * (d1 - margin);
+            nact++;
+          }
+        }
+      }
+      {
+        // equality rows live on joint1's lane and need qpos/qvel of joint2 (an ancestor dof)
+        const double qo = bperm(qpos, eq_other_sa), vo = bperm(qvel, eq_other_sa);
+        if (con_on && eq_own >= 0) {
+          const int jo = m.eq_jnt2[eq_own];
+          const double* cf = m.eq_data + 5 * eq_own;
+          const double x = qo - m.qpos0[jo];
+          const double pos_e = (qpos - qpos0) - (cf[0] + x * (cf[1] + x * (cf[2] + x * (cf[3] + x * cf[4]))));
+          const double deriv = cf[1] + x * (2 * cf[2] + x * (3 * cf[3] + x * 4 * cf[4]));
+          const double diag = m.dof_invweight0[j] + m.dof_invweight0[jo];
+          double K, B;
+          const double imp = tp_impedance(m.eq_solimp + 5 * eq_own, pos_e, 0.0);
+          kb_from_solref(m, m.eq_solref + 2 * eq_own, m.eq_solimp + 5 * eq_own, K, B);
+          r.own = true; r.ce = deriv; r.De = 1.0 / fmax(BS_MINVAL, (1 - imp) * diag / imp);
+          r.aref_e = -B * (qvel - deriv * vo) - K * imp * pos_e;
+          nact++;
+        }
+        const double De_s = bperm(r.De, eq_src_sa), ce_s = bperm(r.ce, eq_src_sa);
+        if (is_src) { r.De_o = De_s; r.ce_o = ce_s; }
+      }
+      nefc = env_sum_i(nact);
+
+      // ---- A11 Newton on the dual-free primal (mj_solNewton shape)
+      double qfrc_constraint = 0, frc[4] = {0, 0, 0, 0};
+      if (nefc == 0) {  // env-uniform
+        qacc = qacc_smooth; qacc_ws = qacc_smooth; solver_iter = 0;
+      } else {
+        TpSol s;
+        auto residual = [&](double a, double sub, double& jf, double& jl0, double& jl1, double& je) {
+          const double ao = bperm(a, eq_other_sa);
+          jf = a - sub * r.aref_f; jl0 = a - sub * r.aref_l0; jl1 = -a - sub * r.aref_l1;
+          je = r.own ? (a - r.ce * ao) - sub * r.aref_e : 0.0;
+        };
+        // warm start: previous acceleration only if cheaper than the unconstrained one
+        // (M qacc_smooth == qfrc_smooth, so its Gauss term vanishes and Ma is known)
+        bool use_smooth = true;
+        double Ma_ws = 0;
+        if (!(m.disableflags & BS_DSBL_WARMSTART)) {
+          Ma_ws = tp_mul_m(c, Mr, qacc_ws);
+          double jf, jl0, jl1, je;
+          residual(qacc_ws, 1.0, jf, jl0, jl1, je);
+          const double cw = env_sum(tp_rows_cost<false>(r, jf, jl0, jl1, je, nullptr) +
+                                    0.5 * (Ma_ws - qfrc_smooth) * (qacc_ws - qacc_smooth));
+          residual(qacc_smooth, 1.0, jf, jl0, jl1, je);
+          const double cs = env_sum(tp_rows_cost<false>(r, jf, jl0, jl1, je, nullptr));
+          use_smooth = cw > cs;
+        }
+        s.qacc = has_dof ? (use_smooth ? qacc_smooth : qacc_ws) : 0.0;
+        s.Ma = use_smooth ? qfrc_smooth : Ma_ws;
+        residual(s.qacc, 1.0, s.jf, s.jl0, s.jl1, s.je);
+        double gauss = 0, cost = 0, oldcost = 0;
+        int iter = 0;
+        bool first = true;
+        while (true) {
+          // constraint update: forces, cost, qfrc_constraint = J^T f, gradient
+          const double cr = tp_rows_cost<true>(r, s.jf, s.jl0, s.jl1, s.je, frc);
+          gauss = env_sum(0.5 * (s.Ma - qfrc_smooth) * (s.qacc - qacc_smooth));
+          cost = gauss + env_sum(cr);
+          {
+            const double fo = bperm(frc[3], eq_src_sa);
+            qfrc_constraint = frc[0] + frc[1] - frc[2] + frc[3];
+            if (is_src) qfrc_constraint -= r.ce_o * fo;
+            if (!has_dof) qfrc_constraint = 0;
+          }
+          s.grad = s.Ma - qfrc_smooth - qfrc_constraint;
+          if (!first) {
+            iter++;
+            const double improvement = scale * (oldcost - cost);
+            const double gradient = scale * sqrt(env_sum(s.grad * s.grad));
+            if (improvement < m.tolerance || gradient < m.tolerance) break;
+          }
+          first = false;
+          if (iter >= m.iterations) break;
+          // H = M + J^T D_active J on the dof-tree sparsity, Newton direction
+          TpRow Hr = Mr;
+          if (has_dof) {
+            double add = 0;
+            if (r.Df > 0 && s.jf > -r.rf && s.jf < r.rf) add += r.Df;
+            if (s.jl0 < 0) add += r.Dl0;
+            if (s.jl1 < 0) add += r.Dl1;
+            if (r.own) {
+              add += r.De;
+#pragma unroll
+              for (int a = 1; a < TP_MAXD; a++)
+                if (a == eq_pos) Hr.r[a] -= r.De * r.ce;
+            }
+            if (is_src) add += r.De_o * r.ce_o * r.ce_o;
+            Hr.r[0] += add;
+          }
+          const TpFac LH = tp_factor(c, Hr);
+          s.search = has_dof ? -tp_solve(c, LH.R, LH.dinv, s.grad) : 0.0;
+          s.Mv = tp_mul_m(c, Mr, s.search);
+          residual(s.search, 0.0, s.vf, s.vl0, s.vl1, s.ve);
+          const double alpha = tp_line_search(m, r, s, gauss, scale, qfrc_smooth);
+          if (alpha == 0) break;
+          s.qacc += alpha * s.search; s.Ma += alpha * s.Mv;
+          s.jf += alpha * s.vf; s.jl0 += alpha * s.vl0; s.jl1 += alpha * s.vl1; s.je += alpha * s.ve;
+          oldcost = cost;
+        }
+        solver_iter = iter;
+        qacc = s.qacc;
+        qacc_ws = s.qacc;
+      }
+      // ================= end of forward pass =================
+
+      if (mode == 0 && stage == 0 && !redone && env_any(has_dof && bad_num(qacc), base)) {  // mj_checkAcc
+        reset_state(); warning |= 4;
+        rk_q0 = qpos; rk_v0 = qvel; rk_t0 = time;
+        redone = true; stage = -1;
+        continue;
+      }
+      if (stage == 0 && step == nsteps - 1 && env_ok && dump >= 1) {
+        // outputs of the step's mj_forward (MuJoCo leaves these from before the integration)
+        if (l < m.nbody) {
+          AT(d.xpos, 3 * b) = pos.x; AT(d.xpos, 3 * b + 1) = pos.y; AT(d.xpos, 3 * b + 2) = pos.z;
+          AT(d.xquat, 4 * b) = quat.w; AT(d.xquat, 4 * b + 1) = quat.x; AT(d.xquat, 4 * b + 2) = quat.y;
+          AT(d.xquat, 4 * b + 3) = quat.z;
+        }
+        if (has_dof) {
+          AT(d.qfrc_bias, j) = qfrc_bias; AT(d.qfrc_passive, j) = qfrc_passive;
+          AT(d.qfrc_actuator, j) = qfrc_actuator; AT(d.qfrc_smooth, j) = qfrc_smooth;
+          AT(d.qacc_smooth, j) = qacc_smooth; AT(d.qfrc_constraint, j) = qfrc_constraint;
+        }
+        if (act >= 0) AT(d.actuator_force, act) = act_force;
+        if (dump >= 2) {
+          if (l < m.nbody) {
+            AT(d.xipos, 3 * b) = xipos.x; AT(d.xipos, 3 * b + 1) = xipos.y; AT(d.xipos, 3 * b + 2) = xipos.z;
+            if (root == b && b > 0) {
+              AT(d.rootcom, 3 * b) = com.x; AT(d.rootcom, 3 * b + 1) = com.y; AT(d.rootcom, 3 * b + 2) = com.z;
+            }
+#pragma unroll
+            for (int k = 0; k < 10; k++) AT(d.cinert, 10 * b + k) = cinert[k];
+#pragma unroll
+            for (int k = 0; k < 6; k++) AT(d.cvel, 6 * b + k) = cvel[k];
+          }
+          if (has_dof) {
+            AT(d.xanchor, 3 * j) = anchor.x; AT(d.xanchor, 3 * j + 1) = anchor.y; AT(d.xanchor, 3 * j + 2) = anchor.z;
+            AT(d.xaxis, 3 * j) = axis.x; AT(d.xaxis, 3 * j + 1) = axis.y; AT(d.xaxis, 3 * j + 2) = axis.z;
+#pragma unroll
+            for (int k = 0; k < 6; k++) AT(d.cdof, 6 * j + k) = cdof[k];
+            const int adr = m.dof_Madr[j];
+#pragma unroll
+            for (int a = 0; a < TP_MAXD; a++)
+              if (a < c.dd) { AT(d.qM, adr + a) = Mr.r[a]; AT(d.qLD, adr + a) = LM.R.r[a]; }
+            AT(d.qLDiagInv, j) = LM.dinv;
+            const int fr = tbl[TPI_FRIC_ROW * 64 + tid], lr = tbl[TPI_LIM_ROW * 64 + tid];
+            if (fr >= 0) AT(d.efc_force, fr) = frc[0];
+            if (lr >= 0) { AT(d.efc_force, lr) = frc[1]; AT(d.efc_force, lr + 1) = frc[2]; }
+            if (eq_own >= 0) AT(d.efc_force, eq_own) = frc[3];
+          }
+        }
+      }
+      if (mode == 1) break;
+      if (nstage == 1) {
+        // ---- A12 Euler with implicit joint damping
+        double acc = qacc;
+        if (m.damped) {
+          TpRow Hr = Mr;
+          Hr.r[0] += h * damping;
+          const TpFac LE = tp_factor(c, Hr);
+          acc = tp_solve(c, LE.R, LE.dinv, has_dof ? qfrc_smooth + qfrc_constraint : 0.0);
+        }
+        qvel += h * acc;
+        qpos += h * qvel;
+        time += h;
+      } else {
+        // ---- A13 RK4, classical tableau: A = diag-below (1/2, 1/2, 1), B = (1/6, 1/3, 1/3, 1/6)
+        const double Bw = (stage == 0 || stage == 3) ? 1.0 / 6.0 : 1.0 / 3.0;
+        rk_dq += Bw * qvel; rk_dv += Bw * qacc;
+        if (stage < 3) {
+          const double A = stage == 2 ? 1.0 : 0.5;
+          const double kq = qvel, kv = qacc;
+          qpos = rk_q0 + h * (A * kq); qvel = rk_v0 + h * (A * kv); time = rk_t0 + A * h;
+        } else {
+          qvel = rk_v0 + h * rk_dv; qpos = rk_q0 + h * rk_dq; time = rk_t0 + h;
+        }
+      }
+    }
+  }
+  if (!env_ok) return;
+  if (has_dof) {
+    AT(d.qpos, j) = qpos; AT(d.qvel, j) = qvel; AT(d.qacc, j) = qacc; AT(d.qacc_warmstart, j) = qacc_ws;
+    if (was_reset) AT(d.qfrc_applied, j) = qfrc_applied;
+  }
+  if (was_reset && act >= 0) AT(d.ctrl, act) = ctrl;
+  if (l == 0) {
+    AT(d.time, 0) = time; AT(d.warning, 0) = warning; AT(d.solver_iter, 0) = solver_iter; AT(d.nefc, 0) = nefc;
+  }
+}
