@@ -194,7 +194,7 @@ def main():
                        "mean_solver_iter": iters, "mean_nefc": nefc, "envs_with_warnings": warn},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None,
-                         "kernel": "k_step", "launch_ms": k_ms, "env_steps_per_launch": E * CTRL_PERIOD,
+                         "kernel": "k_tp", "launch_ms": k_ms, "env_steps_per_launch": E * CTRL_PERIOD,
                          "flop_per_env_step": FLOP_PER_ENV_STEP,
                          "note": "fp64 compute-bound path: peak is the MI355X fp64 vector=matrix rate; "
                                  "algorithmic HBM rate would be "

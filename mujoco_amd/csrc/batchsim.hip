@@ -448,7 +448,7 @@ __global__ __launch_bounds__(BS_BLOCK) void k_step(DevModel m, DevData d, int ns
   for (int s = 0; s < nsteps; s++) env_step(m, d, e);
 }
 // tree-parallel kernel: 2 environments per 64-lane block (physics_tp.h)
-__global__ __launch_bounds__(64) void k_tp(DevModel m, TpModel t, DevData d, int nsteps, int mode, int dump) {
+__global__ __launch_bounds__(64, 2) void k_tp(DevModel m, TpModel t, DevData d, int nsteps, int mode, int dump) {
   __shared__ int tbl[TPI_TOTAL * 64];
   tp_run(m, t, d, nsteps, mode, dump, tbl);
 }
