@@ -93,6 +93,7 @@ typedef enum bs_field {
   BS_F_NEFC,        /* int32 [1][E]: active constraint rows */
   BS_F_XMAT,        /* derived on demand from xquat */
   BS_F_GEOM_XPOS, BS_F_GEOM_XMAT,
+  BS_F_NCON,        /* int32 [1][E]: contacts of the last collision pass (0 rows when contacts are disabled) */
   BS_F_COUNT
 } bs_field;
 
@@ -133,6 +134,11 @@ int bs_copy_field(bs_sim *s, int field_id, void *host, int direction);
 /* sim.data.ncon / sim.data.contact[i].geom1, geom2, dist for one environment. */
 int bs_get_contacts(bs_sim *s, int64_t env, int32_t *geom1, int32_t *geom2, double *dist, int cap,
                     int *n);
+
+/* Work-model counters of the collision stage since creation / last reset:
+ * out[0] narrowphase pairs, out[1] MPR support iterations, out[2] contacts.  No mujoco-py
+ * counterpart (mjData has no such counters); used by bench.py to report N_np and ncon. */
+int bs_collision_stats(bs_sim *s, uint64_t out[3], int reset);
 
 int bs_sync(bs_sim *s);
 /* Runs one step stage by stage with HIP events between the stages and returns the elapsed

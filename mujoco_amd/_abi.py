@@ -47,13 +47,13 @@ class Options(C.Structure):
 FIELD_NAMES = ("qpos qvel ctrl qfrc_applied qacc qacc_warmstart time xpos xquat xipos xanchor xaxis "
                "rootcom cinert crb cdof qM qLD qLDiagInv cvel qfrc_bias qfrc_passive actuator_force "
                "qfrc_actuator qfrc_smooth qacc_smooth qfrc_constraint efc_D efc_aref efc_force "
-               "solver_iter warning nefc xmat geom_xpos geom_xmat").split()
+               "solver_iter warning nefc xmat geom_xpos geom_xmat ncon").split()
 FIELD_ID = {n: i for i, n in enumerate(FIELD_NAMES)}
 
 # every symbol include/batchsim.h declares
 SYMBOLS = ("bs_version bs_last_error bs_device_count bs_model_create bs_model_destroy bs_sim_create "
            "bs_sim_destroy bs_set_stream bs_step bs_forward bs_reset bs_get_ptr bs_copy_field "
-           "bs_get_contacts bs_sync bs_stage_times bs_timed_steps").split()
+           "bs_get_contacts bs_collision_stats bs_sync bs_stage_times bs_timed_steps").split()
 
 
 class BatchSimError(RuntimeError):
@@ -89,6 +89,7 @@ def lib():
                              C.POINTER(C.c_int)]
     L.bs_copy_field.argtypes = [vp, C.c_int, vp, C.c_int]
     L.bs_get_contacts.argtypes = [vp, C.c_int64, _IP, _IP, _DP, C.c_int, C.POINTER(C.c_int)]
+    L.bs_collision_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int]
     L.bs_sync.argtypes = [vp]
     L.bs_stage_times.argtypes = [vp, _DP, C.c_int]
     L.bs_timed_steps.argtypes = [vp, C.c_int, _DP]

@@ -13,6 +13,7 @@
 
 #include "physics_dev.h"
 #include "physics_tp.h"
+#include "physics_contact.h"
 #include <cstdlib>
 
 // ------------------------------------------------------------------ errors
@@ -58,6 +59,7 @@ struct DeviceImage {
   void* blob = nullptr;
   DevModel dm;
   TpModel tp;
+  ColModel cm;
 };
 
 struct bs_model {
@@ -200,6 +202,38 @@ extern "C" int bs_model_create(const bs_model_desc* desc, bs_model** out) {
   CHECK_PTR(dof_armature, nv); CHECK_PTR(dof_damping, nv); CHECK_PTR(dof_frictionloss, nv);
   CHECK_PTR(dof_solref, nv); CHECK_PTR(dof_solimp, nv); CHECK_PTR(dof_invweight0, nv);
   CHECK_PTR(geom_bodyid, ng); CHECK_PTR(geom_pos, ng); CHECK_PTR(geom_quat, ng);
+  CHECK_PTR(geom_type, ng); CHECK_PTR(geom_dataid, ng); CHECK_PTR(geom_condim, ng); CHECK_PTR(geom_rbound, ng);
+  CHECK_PTR(geom_margin, ng); CHECK_PTR(geom_gap, ng); CHECK_PTR(geom_friction, ng); CHECK_PTR(geom_solref, ng);
+  CHECK_PTR(geom_solimp, ng); CHECK_PTR(geom_solmix, ng);
+  CHECK_PTR(pair_geom1, desc->npair); CHECK_PTR(pair_geom2, desc->npair);
+  CHECK_PTR(mesh_vertadr, desc->nmesh); CHECK_PTR(mesh_vertnum, desc->nmesh);
+  CHECK_PTR(hull_vert, desc->nhullvert); CHECK_PTR(hull_adj_start, desc->nhullvert); CHECK_PTR(hull_adj, desc->nhulladj);
+  if (desc->npair < 0 || desc->nmesh < 0 || desc->nhullvert < 0 || desc->nhulladj < 0)
+    return fail(BS_ERR_INVALID, "bs_model_create: negative collision sizes");
+  for (int p = 0; p < desc->npair; p++) {
+    const int g1 = desc->pair_geom1[p], g2 = desc->pair_geom2[p];
+    if (g1 < 0 || g1 >= ng || g2 < 0 || g2 >= ng) return fail(BS_ERR_INVALID, "pair %d: bad geom id", p);
+  }
+  for (int g = 0; g < ng; g++) {
+    if (desc->geom_type[g] == BS_GEOM_MESH) {
+      const int me = desc->geom_dataid[g];
+      if (me < 0 || me >= desc->nmesh) return fail(BS_ERR_INVALID, "geom %d: bad mesh id", g);
+      if (desc->mesh_vertnum[me] < 1 || desc->mesh_vertadr[me] < 0 ||
+          desc->mesh_vertadr[me] + desc->mesh_vertnum[me] > desc->nhullvert)
+        return fail(BS_ERR_INVALID, "mesh %d: bad hull vertex range", me);
+    }
+    if (desc->npair > 0 && !(desc->disableflags & BS_DSBL_CONTACT) && desc->geom_condim[g] != 1 && desc->geom_condim[g] != 3)
+      return fail(BS_ERR_UNSUPPORTED, "geom %d: condim %d (only 1 and 3 are implemented)", g, desc->geom_condim[g]);
+  }
+  for (int me = 0; me < desc->nmesh; me++)
+    for (int v = desc->mesh_vertadr[me]; v < desc->mesh_vertadr[me] + desc->mesh_vertnum[me]; v++) {
+      if (desc->hull_adj_start[v] < 0 || desc->hull_adj_start[v + 1] < desc->hull_adj_start[v] ||
+          desc->hull_adj_start[v + 1] > desc->nhulladj)
+        return fail(BS_ERR_INVALID, "hull vertex %d: bad adjacency range", v);
+      for (int q = desc->hull_adj_start[v]; q < desc->hull_adj_start[v + 1]; q++)
+        if (desc->hull_adj[q] < 0 || desc->hull_adj[q] >= desc->mesh_vertnum[me])
+          return fail(BS_ERR_INVALID, "hull vertex %d: neighbour out of range", v);
+    }
   CHECK_PTR(actuator_trnid, nu); CHECK_PTR(actuator_ctrllimited, nu); CHECK_PTR(actuator_forcelimited, nu);
   CHECK_PTR(actuator_ctrlrange, nu); CHECK_PTR(actuator_forcerange, nu); CHECK_PTR(actuator_gear, nu);
   CHECK_PTR(actuator_gainprm, nu); CHECK_PTR(actuator_biasprm, nu);
@@ -250,7 +284,12 @@ extern "C" int bs_model_create(const bs_model_desc* desc, bs_model** out) {
              {&m->d.jnt_type, (size_t)nj}, {&m->d.jnt_bodyid, (size_t)nj}, {&m->d.jnt_qposadr, (size_t)nj},
              {&m->d.jnt_dofadr, (size_t)nj}, {&m->d.jnt_limited, (size_t)nj}, {&m->d.dof_bodyid, (size_t)nv},
              {&m->d.dof_jntid, (size_t)nv}, {&m->d.dof_parentid, (size_t)nv}, {&m->d.dof_Madr, (size_t)nv},
-             {&m->d.geom_bodyid, (size_t)ng}, {&m->d.actuator_trnid, (size_t)nu},
+             {&m->d.geom_bodyid, (size_t)ng}, {&m->d.geom_type, (size_t)ng}, {&m->d.geom_dataid, (size_t)ng},
+             {&m->d.geom_condim, (size_t)ng}, {&m->d.pair_geom1, (size_t)desc->npair},
+             {&m->d.pair_geom2, (size_t)desc->npair}, {&m->d.mesh_vertadr, (size_t)desc->nmesh},
+             {&m->d.mesh_vertnum, (size_t)desc->nmesh},
+             {&m->d.hull_adj_start, (size_t)(desc->nhullvert > 0 ? desc->nhullvert + 1 : 0)},
+             {&m->d.hull_adj, (size_t)desc->nhulladj}, {&m->d.actuator_trnid, (size_t)nu},
              {&m->d.actuator_ctrllimited, (size_t)nu}, {&m->d.actuator_forcelimited, (size_t)nu},
              {&m->d.eq_obj1id, (size_t)ne}, {&m->d.eq_obj2id, (size_t)ne}, {&m->d.eq_active, (size_t)ne}};
   DA da[] = {{&m->d.body_pos, (size_t)nb * 3}, {&m->d.body_quat, (size_t)nb * 4}, {&m->d.body_ipos, (size_t)nb * 3},
@@ -262,6 +301,10 @@ extern "C" int bs_model_create(const bs_model_desc* desc, bs_model** out) {
              {&m->d.dof_armature, (size_t)nv}, {&m->d.dof_damping, (size_t)nv}, {&m->d.dof_frictionloss, (size_t)nv},
              {&m->d.dof_solref, (size_t)nv * 2}, {&m->d.dof_solimp, (size_t)nv * 5}, {&m->d.dof_invweight0, (size_t)nv},
              {&m->d.geom_pos, (size_t)ng * 3}, {&m->d.geom_quat, (size_t)ng * 4},
+             {&m->d.geom_rbound, (size_t)ng}, {&m->d.geom_margin, (size_t)ng}, {&m->d.geom_gap, (size_t)ng},
+             {&m->d.geom_friction, (size_t)ng * 3}, {&m->d.geom_solref, (size_t)ng * 2},
+             {&m->d.geom_solimp, (size_t)ng * 5}, {&m->d.geom_solmix, (size_t)ng},
+             {&m->d.hull_vert, (size_t)desc->nhullvert * 3},
              {&m->d.actuator_ctrlrange, (size_t)nu * 2}, {&m->d.actuator_forcerange, (size_t)nu * 2},
              {&m->d.actuator_gear, (size_t)nu}, {&m->d.actuator_gainprm, (size_t)nu * 3},
              {&m->d.actuator_biasprm, (size_t)nu * 3}, {&m->d.eq_data, (size_t)ne * 5},
@@ -397,6 +440,23 @@ static int model_image(bs_model* m, int device, const DeviceImage** out) {
   PUT_D(eq_data, m->eq_data.data(), dm.neq * 5); PUT_D(eq_solref, m->eq_solref.data(), dm.neq * 2);
   PUT_D(eq_solimp, m->eq_solimp.data(), dm.neq * 5);
   PUT_I(fric_dof, m->fric_dof.data(), dm.nfric); PUT_I(lim_jnt, m->lim_jnt.data(), dm.nlim);
+  ColModel cm;
+  memset(&cm, 0, sizeof cm);
+  cm.npair = s.npair; cm.ngeom = ng; cm.mpr_iterations = s.mpr_iterations; cm.mpr_tolerance = s.mpr_tolerance;
+#define PUT_CI(dst, src, n) fix.push_back({pk.add(src, (size_t)(n) * sizeof(int32_t)), (void**)&cm.dst})
+#define PUT_CD(dst, src, n) fix.push_back({pk.add(src, (size_t)(n) * sizeof(double)), (void**)&cm.dst})
+  PUT_CI(pair_geom1, s.pair_geom1, s.npair); PUT_CI(pair_geom2, s.pair_geom2, s.npair);
+  PUT_CI(geom_type, s.geom_type, ng); PUT_CI(geom_dataid, s.geom_dataid, ng); PUT_CI(geom_condim, s.geom_condim, ng);
+  PUT_CI(geom_bodyid, s.geom_bodyid, ng);
+  PUT_CD(geom_rbound, s.geom_rbound, ng); PUT_CD(geom_margin, s.geom_margin, ng); PUT_CD(geom_gap, s.geom_gap, ng);
+  PUT_CD(geom_friction, s.geom_friction, ng * 3); PUT_CD(geom_solref, s.geom_solref, ng * 2);
+  PUT_CD(geom_solimp, s.geom_solimp, ng * 5); PUT_CD(geom_solmix, s.geom_solmix, ng);
+  PUT_CD(hull_vert, s.hull_vert, s.nhullvert * 3);
+  PUT_CI(mesh_vertadr, s.mesh_vertadr, s.nmesh);
+  PUT_CI(hull_adj_start, s.hull_adj_start, s.nhullvert > 0 ? s.nhullvert + 1 : 0);
+  PUT_CI(hull_adj, s.hull_adj, s.nhulladj);
+#undef PUT_CI
+#undef PUT_CD
   TpModel tp = m->tp;
   tp.lane = nullptr;
   if (m->tp_ok) fix.push_back({pk.add(m->tp_table.data(), m->tp_table.size() * sizeof(int32_t)), (void**)&tp.lane});
@@ -408,7 +468,7 @@ static int model_image(bs_model* m, int device, const DeviceImage** out) {
   HIPCHK(hipMemcpy(blob, pk.bytes.data(), pk.bytes.size(), hipMemcpyHostToDevice));
   for (auto& f : fix) *f.slot = (char*)blob + f.off;
   DeviceImage im;
-  im.device = device; im.blob = blob; im.dm = dm; im.tp = tp;
+  im.device = device; im.blob = blob; im.dm = dm; im.tp = tp; im.cm = cm;
   m->images.push_back(im);
   *out = &m->images.back();
   return BS_OK;
@@ -426,6 +486,11 @@ struct bs_sim {
   DevModel dm;
   TpModel tp;
   bool use_tp = false;
+  bool contacts = false;
+  ColModel cm;
+  ColData cd;
+  ConData kd;
+  void* carena = nullptr;
   DevData dd;
   int device = 0;
   long n_envs = 0, E = 0;
@@ -510,9 +575,55 @@ __global__ __launch_bounds__(BS_BLOCK) void k_frames(DevModel m, DevData d, doub
   }
 }
 
+// ---- contact pipeline (serial layout): position -> broadphase -> narrowphase -> dynamics
+__global__ __launch_bounds__(BS_BLOCK) void k_c_pos(DevModel m, DevData d, ColData c, int check) {
+  const long e = (long)blockIdx.x * BS_BLOCK + threadIdx.x;
+  if (e >= d.n_envs) return;
+  if (check) {
+    env_check(m, d, e, d.qpos, m.njnt, 0);
+    env_check(m, d, e, d.qvel, m.nv, 1);
+  }
+  stage_position(m, d, e);
+  stage_factor(m, d, e);
+  col_geom_frames(m, d, c, e);
+}
+__global__ __launch_bounds__(64) void k_c_broad(ColModel cm, DevData d, ColData c) {
+  const long e = blockIdx.x;  // one wavefront per environment
+  if (e >= d.n_envs) return;
+  col_broadphase(cm, d, c, e, threadIdx.x);
+}
+__global__ __launch_bounds__(BS_BLOCK) void k_c_narrow(ColModel cm, DevData d, ColData c) {
+  const long e = (long)blockIdx.x * BS_BLOCK + threadIdx.x;
+  if (e >= d.n_envs) return;
+  col_narrowphase(cm, d, c, e, blockIdx.y);
+}
+__global__ __launch_bounds__(BS_BLOCK) void k_c_dyn(DevModel m, ColModel cm, DevData d, ColData c, ConData k,
+                                                    int integrate) {
+  const long e = (long)blockIdx.x * BS_BLOCK + threadIdx.x;
+  if (e >= d.n_envs) return;
+  col_assemble(cm, d, c, e);
+  stage_velocity(m, d, e);
+  stage_constraint_c(m, cm, d, c, k, e);
+  if (integrate) {
+    // mj_checkAcc: a bad acceleration resets the environment; the next step recomputes everything
+    if (!env_check(m, d, e, d.qacc, m.nv, 2)) stage_euler(m, d, e);
+  }
+}
+
 static inline dim3 grid_for(const bs_sim* s) { return dim3((unsigned)((s->n_envs + BS_BLOCK - 1) / BS_BLOCK)); }
 static inline dim3 grid_tp(const bs_sim* s) { return dim3((unsigned)((s->n_envs + 1) / 2)); }
+static void launch_contact_pass(bs_sim* s, int check, int integrate) {
+  const dim3 g = dim3((unsigned)((s->n_envs + BS_BLOCK - 1) / BS_BLOCK));
+  hipLaunchKernelGGL(k_c_pos, g, dim3(BS_BLOCK), 0, s->stream, s->dm, s->dd, s->cd, check);
+  hipLaunchKernelGGL(k_c_broad, dim3((unsigned)s->n_envs), dim3(64), 0, s->stream, s->cm, s->dd, s->cd);
+  hipLaunchKernelGGL(k_c_narrow, dim3(g.x, (unsigned)s->cm.maxcand), dim3(BS_BLOCK), 0, s->stream, s->cm, s->dd, s->cd);
+  hipLaunchKernelGGL(k_c_dyn, g, dim3(BS_BLOCK), 0, s->stream, s->dm, s->cm, s->dd, s->cd, s->kd, integrate);
+}
 static void launch_step(bs_sim* s, int n_steps) {
+  if (s->contacts) {
+    for (int k = 0; k < n_steps; k++) launch_contact_pass(s, 1, 1);
+    return;
+  }
   if (s->use_tp)
     hipLaunchKernelGGL(k_tp, grid_tp(s), dim3(64), 0, s->stream, s->dm, s->tp, s->dd, n_steps, 0, 1);
   else
@@ -537,11 +648,10 @@ extern "C" int bs_sim_create(const bs_model* const* models, int n_models, const 
   }
   if (device < 0 || device >= ndev) return fail(BS_ERR_INVALID, "bs_sim_create: device %d out of range [0,%d)", device, ndev);
   bs_model* model = const_cast<bs_model*>(models[0]);
-  if (!(model->d.disableflags & BS_DSBL_CONTACT) && model->d.npair > 0)
-    return fail(BS_ERR_UNSUPPORTED,
-                "bs_sim_create: the collision stage (A5/A6) is not on the device yet; this model has %d "
-                "candidate geom pairs - disable contacts (<flag contact=\"disable\"/>) to step it joint-space only",
-                model->d.npair);
+  const bool contacts = !(model->d.disableflags & BS_DSBL_CONTACT) && !(model->d.disableflags & BS_DSBL_CONSTRAINT) &&
+                        model->d.npair > 0;
+  if (contacts && model->d.integrator == 1)
+    return fail(BS_ERR_UNSUPPORTED, "bs_sim_create: RK4 with contacts is not implemented (use Euler or disable contacts)");
   const DeviceImage* img = nullptr;
   int rc = model_image(model, device, &img);
   if (rc) return rc;
@@ -549,7 +659,11 @@ extern "C" int bs_sim_create(const bs_model* const* models, int n_models, const 
   bs_sim* s = new bs_sim();
   s->model = model; s->dm = img->dm; s->tp = img->tp; s->device = device; s->n_envs = n_envs;
   const char* kv = getenv("BS_KERNEL");
-  s->use_tp = model->tp_ok && !(kv && strcmp(kv, "serial") == 0);
+  s->contacts = contacts;
+  s->cm = img->cm;
+  s->cm.maxcon = (opt && opt->max_contacts_per_env > 0) ? opt->max_contacts_per_env : 32;
+  s->cm.maxcand = model->d.npair < 256 ? model->d.npair : 256;
+  s->use_tp = !contacts && model->tp_ok && !(kv && strcmp(kv, "serial") == 0);
   if (kv && strcmp(kv, "tp") == 0 && !model->tp_ok) {
     delete s;
     return fail(BS_ERR_UNSUPPORTED, "BS_KERNEL=tp but the model is not eligible: %s", model->tp_why.c_str());
@@ -614,6 +728,41 @@ extern "C" int bs_sim_create(const bs_model* const* models, int n_models, const 
   s->fields[BS_F_SOLVER_ITER] = {d.solver_iter, 1, true};
   s->fields[BS_F_WARNING] = {d.warning, 1, true};
   s->fields[BS_F_NEFC] = {d.nefc, 1, true};
+  memset(&s->cd, 0, sizeof s->cd);
+  memset(&s->kd, 0, sizeof s->kd);
+  s->cd.geom_xpos = (double*)s->fields[BS_F_GEOM_XPOS].ptr;
+  s->cd.geom_xmat = (double*)s->fields[BS_F_GEOM_XMAT].ptr;
+  if (contacts) {
+    const size_t mc = (size_t)s->cm.maxcand, mk = (size_t)s->cm.maxcon, nr = 4 * mk, nh = (size_t)nv * (nv + 1) / 2;
+    const size_t drows = mc * 7 + mk * 13 + nr * nv + nr * 5 + nh;
+    const size_t irows = 1 + mc * 2 + 1 + mk + 1 + mk;
+    const size_t bytes = drows * E * sizeof(double) + irows * E * sizeof(int) + 64;
+    he = hipMalloc(&s->carena, bytes);
+    if (he != hipSuccess) {
+      (void)hipFree(s->arena); (void)hipStreamDestroy(s->own_stream);
+      delete s;
+      return fail(BS_ERR_NOMEM, "bs_sim_create: hipMalloc of %zu bytes for the contact arena failed: %s", bytes,
+                  hipGetErrorString(he));
+    }
+    HIPCHK(hipMemset(s->carena, 0, bytes));
+    double* dp = (double*)s->carena;
+    auto take = [&](size_t rows_) { double* q = dp; dp += rows_ * (size_t)E; return q; };
+    ColData& c = s->cd;
+    ConData& k = s->kd;
+    c.cand_dist = take(mc); c.cand_pos = take(3 * mc); c.cand_nrm = take(3 * mc);
+    c.con_dist = take(mk); c.con_pos = take(3 * mk); c.con_frame = take(9 * mk);
+    k.cJ = take(nr * nv); k.cD = take(nr); k.caref = take(nr); k.cjar = take(nr); k.cjv = take(nr); k.cforce = take(nr);
+    k.Hd = take(nh);
+    int* ip = (int*)dp;
+    auto takei = [&](size_t rows_) { int* q = ip; ip += rows_ * (size_t)E; return q; };
+    c.ncand = takei(1); c.cand_pair = takei(mc); c.cand_hit = takei(mc);
+    c.ncon = takei(1); c.con_pair = takei(mk);
+    k.ncrow = takei(1); k.con_efc = takei(mk);
+    c.stat = (unsigned long long*)(((uintptr_t)ip + 7) & ~(uintptr_t)7);
+    s->fields[BS_F_NCON] = {c.ncon, 1, true};
+  } else {
+    s->fields[BS_F_NCON] = {d.nefc, 0, true};  // zero rows: no contacts in this sim
+  }
   for (auto& ev : s->ev) HIPCHK(hipEventCreate(&ev));
   s->events = true;
   hipLaunchKernelGGL(k_reset, grid_for(s), dim3(BS_BLOCK), 0, s->stream, s->dm, s->dd, (const uint8_t*)nullptr);
@@ -630,6 +779,7 @@ extern "C" int bs_sim_destroy(bs_sim* s) {
   if (s->events)
     for (auto& ev : s->ev) (void)hipEventDestroy(ev);
   if (s->arena) (void)hipFree(s->arena);
+  if (s->carena) (void)hipFree(s->carena);
   if (s->own_stream) (void)hipStreamDestroy(s->own_stream);
   delete s;
   return BS_OK;
@@ -656,7 +806,9 @@ extern "C" int bs_step(bs_sim* s, int n_steps) {
 extern "C" int bs_forward(bs_sim* s) {
   if (!s) return fail(BS_ERR_INVALID, "bs_forward: null sim");
   HIPCHK(hipSetDevice(s->device));
-  if (s->use_tp)
+  if (s->contacts)
+    launch_contact_pass(s, 0, 0);
+  else if (s->use_tp)
     hipLaunchKernelGGL(k_tp, grid_tp(s), dim3(64), 0, s->stream, s->dm, s->tp, s->dd, 1, 1, 2);
   else
     hipLaunchKernelGGL(k_forward, grid_for(s), dim3(BS_BLOCK), 0, s->stream, s->dm, s->dd);
@@ -732,10 +884,39 @@ extern "C" int bs_copy_field(bs_sim* s, int field_id, void* host, int direction)
 
 extern "C" int bs_get_contacts(bs_sim* s, int64_t env, int32_t* geom1, int32_t* geom2, double* dist, int cap,
                                int* n) {
-  (void)geom1; (void)geom2; (void)dist; (void)cap;
   if (!s || !n) return fail(BS_ERR_INVALID, "bs_get_contacts: null argument");
   if (env < 0 || env >= s->n_envs) return fail(BS_ERR_INVALID, "bs_get_contacts: env %lld out of range", (long long)env);
-  *n = 0;  // the collision stage (A5/A6) is not on the device yet: contact-free step only
+  *n = 0;
+  if (!s->contacts) return BS_OK;
+  if (cap < 0 || (cap > 0 && (!geom1 || !geom2 || !dist))) return fail(BS_ERR_INVALID, "bs_get_contacts: null output");
+  HIPCHK(hipSetDevice(s->device));
+  HIPCHK(hipStreamSynchronize(s->stream));
+  int nc = 0;
+  HIPCHK(hipMemcpy(&nc, s->cd.ncon + env, sizeof(int), hipMemcpyDeviceToHost));
+  if (nc > s->cm.maxcon) nc = s->cm.maxcon;
+  *n = nc;
+  const int m = nc < cap ? nc : cap;
+  if (m <= 0) return BS_OK;
+  std::vector<int> pr(m);
+  HIPCHK(hipMemcpy2D(pr.data(), sizeof(int), s->cd.con_pair + env, (size_t)s->E * sizeof(int), sizeof(int), (size_t)m,
+                     hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy2D(dist, sizeof(double), s->cd.con_dist + env, (size_t)s->E * sizeof(double), sizeof(double),
+                     (size_t)m, hipMemcpyDeviceToHost));
+  for (int i = 0; i < m; i++) {
+    geom1[i] = s->model->d.pair_geom1[pr[i]];
+    geom2[i] = s->model->d.pair_geom2[pr[i]];
+  }
+  return BS_OK;
+}
+
+extern "C" int bs_collision_stats(bs_sim* s, uint64_t out[3], int reset) {
+  if (!s || !out) return fail(BS_ERR_INVALID, "bs_collision_stats: null argument");
+  out[0] = out[1] = out[2] = 0;
+  if (!s->contacts) return BS_OK;
+  HIPCHK(hipSetDevice(s->device));
+  HIPCHK(hipStreamSynchronize(s->stream));
+  HIPCHK(hipMemcpy(out, s->cd.stat, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  if (reset) HIPCHK(hipMemset(s->cd.stat, 0, 3 * sizeof(uint64_t)));
   return BS_OK;
 }
 
@@ -749,6 +930,23 @@ extern "C" int bs_sync(bs_sim* s) {
 extern "C" int bs_stage_times(bs_sim* s, double* ms, int n) {
   if (!s || !ms || n < 5) return fail(BS_ERR_INVALID, "bs_stage_times: need room for 5 stage times");
   HIPCHK(hipSetDevice(s->device));
+  if (s->contacts) {
+    const dim3 g = dim3((unsigned)((s->n_envs + BS_BLOCK - 1) / BS_BLOCK));
+    HIPCHK(hipEventRecord(s->ev[0], s->stream));
+    hipLaunchKernelGGL(k_c_pos, g, dim3(BS_BLOCK), 0, s->stream, s->dm, s->dd, s->cd, 1);
+    HIPCHK(hipEventRecord(s->ev[1], s->stream));
+    hipLaunchKernelGGL(k_c_broad, dim3((unsigned)s->n_envs), dim3(64), 0, s->stream, s->cm, s->dd, s->cd);
+    hipLaunchKernelGGL(k_c_narrow, dim3(g.x, (unsigned)s->cm.maxcand), dim3(BS_BLOCK), 0, s->stream, s->cm, s->dd, s->cd);
+    HIPCHK(hipEventRecord(s->ev[2], s->stream));
+    hipLaunchKernelGGL(k_c_dyn, g, dim3(BS_BLOCK), 0, s->stream, s->dm, s->cm, s->dd, s->cd, s->kd, 1);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(s->ev[3], s->stream));
+    HIPCHK(hipEventSynchronize(s->ev[3]));
+    float t[3];
+    for (int k = 0; k < 3; k++) HIPCHK(hipEventElapsedTime(&t[k], s->ev[k], s->ev[k + 1]));
+    ms[0] = t[0]; ms[1] = t[1]; ms[2] = 0.0; ms[3] = t[2]; ms[4] = 0.0;  // velocity+constraint+integrate fused in [3]
+    return BS_OK;
+  }
   const int stages[4] = {0, 2, 3, 4};
   HIPCHK(hipEventRecord(s->ev[0], s->stream));
   for (int k = 0; k < 4; k++) {

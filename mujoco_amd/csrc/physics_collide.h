@@ -1,0 +1,374 @@
+// physics_collide.h — collision stage on the device.
+//
+// A5 broadphase: one wavefront per environment tests the model's compile-time candidate pair
+// list (reference output/DexterousDynamos.xml:138-159 excludes, contype/conaffinity of
+// src/Mujoco_XML.py:70 already applied) with bounding spheres and writes an ORDERED candidate
+// list per environment using wavefront ballots + popcount prefix sums (deterministic order).
+// A6 narrowphase: one lane per (environment, candidate): Minkowski Portal Refinement on the
+// convex hulls (each inflated by margin/2), support by hill climbing over the hull vertex graph;
+// plane-hull = deepest vertex.  Hull data (~270 KB fp64 for the 12 distinct meshes) stays in L2.
+// Contact assembly: one lane per environment compacts the hits in candidate order.
+//
+// [EXT] restates MuJoCo 2.1.0's mjc_Convex (libccd MPR) / mjc_PlaneConvex from published
+// descriptions; parity is against oracle/oracle_collide.c (PARITY UNPINNED vs MuJoCo).
+#pragma once
+#include "physics_dev.h"
+
+#define BS_CCD_EPS 2.220446049250313e-16
+enum { BS_GEOM_PLANE = 0, BS_GEOM_MESH = 7 };
+
+struct ColModel {
+  int npair, ngeom, maxcand, maxcon, mpr_iterations;
+  double mpr_tolerance;
+  const int *pair_geom1, *pair_geom2, *geom_type, *geom_dataid, *geom_condim, *geom_bodyid;
+  const double *geom_rbound, *geom_margin, *geom_gap, *geom_friction, *geom_solref, *geom_solimp,
+      *geom_solmix, *hull_vert;
+  const int *mesh_vertadr, *hull_adj_start, *hull_adj;
+};
+
+struct ColData {
+  // geom frames (the sim's derived buffers)
+  double *geom_xpos, *geom_xmat;
+  // candidates [maxcand][E]
+  int *ncand, *cand_pair, *cand_hit;
+  double *cand_dist, *cand_pos, *cand_nrm;
+  // contacts [maxcon][E]
+  int *ncon, *con_pair;
+  double *con_dist, *con_pos, *con_frame;
+  // statistics for the work model: narrowphase pairs and MPR support iterations
+  unsigned long long *stat;  // [0] narrow pairs, [1] mpr iterations, [2] contacts
+};
+
+__device__ __forceinline__ bool c_is_zero(double x) { return fabs(x) < BS_CCD_EPS; }
+__device__ __forceinline__ bool c_is_eq(double a, double b) {
+  const double ab = fabs(a - b);
+  if (ab < BS_CCD_EPS) return true;
+  return ab < BS_CCD_EPS * fmax(fabs(a), fabs(b));
+}
+__device__ __forceinline__ double dot(const V3& a, const V3& b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ V3 sub(const V3& a, const V3& b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ V3 neg(const V3& a) { return {-a.x, -a.y, -a.z}; }
+__device__ __forceinline__ V3 normalized(const V3& a) {
+  const double n = sqrt(dot(a, a));
+  if (n > 0) return {a.x / n, a.y / n, a.z / n};
+  return a;
+}
+__device__ __forceinline__ bool v_eq(const V3& a, const V3& b) {
+  return c_is_eq(a.x, b.x) && c_is_eq(a.y, b.y) && c_is_eq(a.z, b.z);
+}
+
+struct CObj {
+  const double* vert;
+  const int *adj_start, *adj;
+  int vertadr, cache;
+  V3 xpos;
+  M3 R;
+  double margin;
+};
+struct Spt { V3 v, v1, v2; };
+
+__device__ inline V3 hull_support(CObj& o, const V3& dir) {
+  const M3& R = o.R;
+  const V3 d = {R.a[0] * dir.x + R.a[3] * dir.y + R.a[6] * dir.z, R.a[1] * dir.x + R.a[4] * dir.y + R.a[7] * dir.z,
+                R.a[2] * dir.x + R.a[5] * dir.y + R.a[8] * dir.z};
+  int imax = o.cache, prev = -1;
+  const double* v0 = o.vert + 3 * imax;
+  double vmax = v0[0] * d.x + v0[1] * d.y + v0[2] * d.z;
+  while (imax != prev) {
+    prev = imax;
+    const int g = o.vertadr + prev;
+    const int k1 = o.adj_start[g + 1];
+    for (int k = o.adj_start[g]; k < k1; k++) {
+      const int nb = o.adj[k];
+      const double* v = o.vert + 3 * nb;
+      const double val = v[0] * d.x + v[1] * d.y + v[2] * d.z;
+      if (val > vmax) { vmax = val; imax = nb; }
+    }
+  }
+  o.cache = imax;
+  const V3 v = ld3(o.vert + 3 * imax);
+  const V3 w = mrot(R, v);
+  return {o.xpos.x + w.x + o.margin * dir.x, o.xpos.y + w.y + o.margin * dir.y, o.xpos.z + w.z + o.margin * dir.z};
+}
+__device__ inline Spt md_support(CObj& a, CObj& b, const V3& dir) {
+  Spt s;
+  s.v1 = hull_support(a, dir);
+  s.v2 = hull_support(b, neg(dir));
+  s.v = sub(s.v1, s.v2);
+  return s;
+}
+__device__ __forceinline__ V3 portal_dir(const Spt* P) {
+  return normalized(cross(sub(P[2].v, P[1].v), sub(P[3].v, P[1].v)));
+}
+__device__ __forceinline__ bool reach_tol(const Spt* P, const Spt& v4, const V3& dir, double tol) {
+  const double dv4 = dot(v4.v, dir);
+  const double m = fmin(fmin(dv4 - dot(P[1].v, dir), dv4 - dot(P[2].v, dir)), dv4 - dot(P[3].v, dir));
+  return c_is_eq(m, tol) || m < tol;
+}
+__device__ __forceinline__ void expand_portal(Spt* P, const Spt& v4) {
+  const V3 v4v0 = cross(v4.v, P[0].v);
+  if (dot(P[1].v, v4v0) > 0) {
+    if (dot(P[2].v, v4v0) > 0) P[1] = v4;
+    else P[3] = v4;
+  } else {
+    if (dot(P[3].v, v4v0) > 0) P[2] = v4;
+    else P[1] = v4;
+  }
+}
+__device__ inline double origin_tri_dist2(const V3& a, const V3& b, const V3& c, V3& w) {
+  const V3 ab = sub(b, a), ac = sub(c, a), ap = neg(a);
+  const double d1 = dot(ab, ap), d2 = dot(ac, ap);
+  if (d1 <= 0 && d2 <= 0) { w = a; return dot(w, w); }
+  const V3 bp = neg(b);
+  const double d3 = dot(ab, bp), d4 = dot(ac, bp);
+  if (d3 >= 0 && d4 <= d3) { w = b; return dot(w, w); }
+  const double vc = d1 * d4 - d3 * d2;
+  if (vc <= 0 && d1 >= 0 && d3 <= 0) {
+    const double v = d1 / (d1 - d3);
+    w = {a.x + v * ab.x, a.y + v * ab.y, a.z + v * ab.z};
+    return dot(w, w);
+  }
+  const V3 cp = neg(c);
+  const double d5 = dot(ab, cp), d6 = dot(ac, cp);
+  if (d6 >= 0 && d5 <= d6) { w = c; return dot(w, w); }
+  const double vb = d5 * d2 - d1 * d6;
+  if (vb <= 0 && d2 >= 0 && d6 <= 0) {
+    const double v = d2 / (d2 - d6);
+    w = {a.x + v * ac.x, a.y + v * ac.y, a.z + v * ac.z};
+    return dot(w, w);
+  }
+  const double va = d3 * d6 - d5 * d4;
+  if (va <= 0 && (d4 - d3) >= 0 && (d5 - d6) >= 0) {
+    const double v = (d4 - d3) / ((d4 - d3) + (d5 - d6));
+    w = {b.x + v * (c.x - b.x), b.y + v * (c.y - b.y), b.z + v * (c.z - b.z)};
+    return dot(w, w);
+  }
+  const double den = 1.0 / (va + vb + vc), v = vb * den, u = vc * den;
+  w = {a.x + ab.x * v + ac.x * u, a.y + ab.y * v + ac.y * u, a.z + ab.z * v + ac.z * u};
+  return dot(w, w);
+}
+
+// returns true when the inflated hulls intersect; fills depth, dir (unit, obj1 -> obj2), pos
+__device__ inline bool mpr_penetration(CObj& a, CObj& b, double tol, int maxit, double& depth, V3& dir, V3& pos,
+                                       int& iters) {
+  Spt P[4];
+  const V3 origin = {0, 0, 0};
+  P[0].v1 = a.xpos; P[0].v2 = b.xpos; P[0].v = sub(P[0].v1, P[0].v2);
+  if (v_eq(P[0].v, origin)) P[0].v = {BS_CCD_EPS * 10, 0, 0};
+  V3 d = normalized(neg(P[0].v));
+  P[1] = md_support(a, b, d);
+  double dt = dot(P[1].v, d);
+  if (c_is_zero(dt) || dt < 0) return false;
+  d = cross(P[0].v, P[1].v);
+  if (c_is_zero(dot(d, d))) {
+    pos = {0.5 * (P[1].v1.x + P[1].v2.x), 0.5 * (P[1].v1.y + P[1].v2.y), 0.5 * (P[1].v1.z + P[1].v2.z)};
+    if (v_eq(P[1].v, origin)) { depth = 0; dir = origin; return true; }  // touching
+    depth = sqrt(dot(P[1].v, P[1].v));
+    dir = normalized(P[1].v);
+    return true;  // origin on the segment v0-v1
+  }
+  d = normalized(d);
+  P[2] = md_support(a, b, d);
+  dt = dot(P[2].v, d);
+  if (c_is_zero(dt) || dt < 0) return false;
+  d = normalized(cross(sub(P[1].v, P[0].v), sub(P[2].v, P[0].v)));
+  if (dot(d, P[0].v) > 0) {
+    const Spt t = P[1]; P[1] = P[2]; P[2] = t;
+    d = neg(d);
+  }
+  int guard = 0;
+  for (;;) {
+    if (++guard > 100) return false;
+    P[3] = md_support(a, b, d);
+    dt = dot(P[3].v, d);
+    if (c_is_zero(dt) || dt < 0) return false;
+    bool cont = false;
+    double x = dot(cross(P[1].v, P[3].v), P[0].v);
+    if (x < 0 && !c_is_zero(x)) { P[2] = P[3]; cont = true; }
+    if (!cont) {
+      x = dot(cross(P[3].v, P[2].v), P[0].v);
+      if (x < 0 && !c_is_zero(x)) { P[1] = P[3]; cont = true; }
+    }
+    if (!cont) break;
+    d = normalized(cross(sub(P[1].v, P[0].v), sub(P[2].v, P[0].v)));
+  }
+  // refine the portal until it encloses the origin
+  bool inside = false;
+  for (int it = 0; it <= maxit + 1; it++) {
+    d = portal_dir(P);
+    const double x = dot(d, P[1].v);
+    if (c_is_zero(x) || x > 0) { inside = true; break; }
+    const Spt v4 = md_support(a, b, d);
+    iters++;
+    const double y = dot(v4.v, d);
+    if (!(c_is_zero(y) || y > 0) || reach_tol(P, v4, d, tol)) return false;
+    expand_portal(P, v4);
+  }
+  if (!inside) return false;
+  // penetration: push the portal to the surface
+  for (int it = 0;; it++) {
+    d = portal_dir(P);
+    const Spt v4 = md_support(a, b, d);
+    iters++;
+    if (reach_tol(P, v4, d, tol) || it > maxit) {
+      V3 w;
+      depth = sqrt(origin_tri_dist2(P[1].v, P[2].v, P[3].v, w));
+      dir = c_is_zero(depth) ? origin : normalized(w);
+      // position from barycentric coordinates of the origin in the portal tetrahedron
+      double bb[4];
+      bb[0] = dot(cross(P[1].v, P[2].v), P[3].v);
+      bb[1] = dot(cross(P[3].v, P[2].v), P[0].v);
+      bb[2] = dot(cross(P[0].v, P[1].v), P[3].v);
+      bb[3] = dot(cross(P[2].v, P[1].v), P[0].v);
+      double sum = bb[0] + bb[1] + bb[2] + bb[3];
+      if (c_is_zero(sum) || sum < 0) {
+        bb[0] = 0;
+        bb[1] = dot(cross(P[2].v, P[3].v), d);
+        bb[2] = dot(cross(P[3].v, P[1].v), d);
+        bb[3] = dot(cross(P[1].v, P[2].v), d);
+        sum = bb[1] + bb[2] + bb[3];
+      }
+      const double inv = 1.0 / sum;
+      V3 p1 = {0, 0, 0}, p2 = {0, 0, 0};
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        p1.x += bb[i] * P[i].v1.x; p1.y += bb[i] * P[i].v1.y; p1.z += bb[i] * P[i].v1.z;
+        p2.x += bb[i] * P[i].v2.x; p2.y += bb[i] * P[i].v2.y; p2.z += bb[i] * P[i].v2.z;
+      }
+      pos = {0.5 * (p1.x * inv + p2.x * inv), 0.5 * (p1.y * inv + p2.y * inv), 0.5 * (p1.z * inv + p2.z * inv)};
+      return true;
+    }
+    expand_portal(P, v4);
+  }
+}
+
+// ---------------------------------------------------------------- kernels' bodies
+// geom frames for one environment lane (same arithmetic as k_frames, geoms only)
+__device__ inline void col_geom_frames(const DevModel& m, const DevData& d, const ColData& c, long e) {
+  const long E = d.E;
+  for (int g = 0; g < m.ngeom; g++) {
+    const int b = m.geom_bodyid[g];
+    const Q4 q = {AT(d.xquat, 4 * b), AT(d.xquat, 4 * b + 1), AT(d.xquat, 4 * b + 2), AT(d.xquat, 4 * b + 3)};
+    const V3 p = mrot(q2m(q), ld3(m.geom_pos + 3 * g));
+    AT(c.geom_xpos, 3 * g) = AT(d.xpos, 3 * b) + p.x;
+    AT(c.geom_xpos, 3 * g + 1) = AT(d.xpos, 3 * b + 1) + p.y;
+    AT(c.geom_xpos, 3 * g + 2) = AT(d.xpos, 3 * b + 2) + p.z;
+    const M3 G = q2m(qmul(q, ld4(m.geom_quat + 4 * g)));
+    for (int k = 0; k < 9; k++) AT(c.geom_xmat, 9 * g + k) = G.a[k];
+  }
+}
+
+// A5: one 64-lane wavefront per environment; ordered compaction with ballot + popcount
+__device__ inline void col_broadphase(const ColModel& cm, const DevData& d, const ColData& c, long e, int lane) {
+  const long E = d.E;
+  int count = 0;
+  for (int p0 = 0; p0 < cm.npair; p0 += 64) {
+    const int p = p0 + lane;
+    bool keep = false;
+    if (p < cm.npair) {
+      const int g1 = cm.pair_geom1[p], g2 = cm.pair_geom2[p];
+      const double margin = fmax(cm.geom_margin[g1], cm.geom_margin[g2]);
+      const double r1 = cm.geom_rbound[g1], r2 = cm.geom_rbound[g2];
+      const V3 x1 = {AT(c.geom_xpos, 3 * g1), AT(c.geom_xpos, 3 * g1 + 1), AT(c.geom_xpos, 3 * g1 + 2)};
+      const V3 x2 = {AT(c.geom_xpos, 3 * g2), AT(c.geom_xpos, 3 * g2 + 1), AT(c.geom_xpos, 3 * g2 + 2)};
+      keep = true;
+      if (r1 > 0 && r2 > 0) {
+        const V3 df = sub(x1, x2);
+        keep = !(sqrt(dot(df, df)) > margin + r1 + r2);
+      } else if (cm.geom_type[g1] == BS_GEOM_PLANE && r2 > 0) {
+        const V3 n = {AT(c.geom_xmat, 9 * g1 + 2), AT(c.geom_xmat, 9 * g1 + 5), AT(c.geom_xmat, 9 * g1 + 8)};
+        keep = !(dot(sub(x2, x1), n) > margin + r2);
+      }
+      const int t1 = cm.geom_type[g1], t2 = cm.geom_type[g2];
+      if (!((t1 == BS_GEOM_PLANE || t1 == BS_GEOM_MESH) && t2 == BS_GEOM_MESH)) keep = false;
+    }
+    const unsigned long long mask = __ballot(keep);
+    const int pos = count + __popcll(mask & ((1ull << lane) - 1ull));
+    if (keep && pos < cm.maxcand) AT(c.cand_pair, pos) = p;
+    count += __popcll(mask);
+  }
+  if (lane == 0) {
+    if (count > cm.maxcand) { count = cm.maxcand; AT(d.warning, 0) |= 8; }
+    AT(c.ncand, 0) = count;
+  }
+}
+
+// A6: one lane per (environment, candidate slot)
+__device__ inline void col_narrowphase(const ColModel& cm, const DevData& d, const ColData& c, long e, int slot) {
+  const long E = d.E;
+  if (slot >= AT(c.ncand, 0)) return;
+  const int p = AT(c.cand_pair, slot);
+  const int g1 = cm.pair_geom1[p], g2 = cm.pair_geom2[p];
+  const double margin = fmax(cm.geom_margin[g1], cm.geom_margin[g2]);
+  CObj b;
+  {
+    const int mesh = cm.geom_dataid[g2];
+    b.vertadr = cm.mesh_vertadr[mesh];
+    b.vert = cm.hull_vert + 3 * (size_t)b.vertadr;
+    b.adj_start = cm.hull_adj_start; b.adj = cm.hull_adj; b.cache = 0;
+    b.xpos = {AT(c.geom_xpos, 3 * g2), AT(c.geom_xpos, 3 * g2 + 1), AT(c.geom_xpos, 3 * g2 + 2)};
+    for (int k = 0; k < 9; k++) b.R.a[k] = AT(c.geom_xmat, 9 * g2 + k);
+  }
+  bool hit = false;
+  double dist = 0;
+  V3 pos = {0, 0, 0}, nrm = {0, 0, 0};
+  if (cm.geom_type[g1] == BS_GEOM_PLANE) {
+    b.margin = 0;
+    const V3 n = {AT(c.geom_xmat, 9 * g1 + 2), AT(c.geom_xmat, 9 * g1 + 5), AT(c.geom_xmat, 9 * g1 + 8)};
+    const V3 pp = {AT(c.geom_xpos, 3 * g1), AT(c.geom_xpos, 3 * g1 + 1), AT(c.geom_xpos, 3 * g1 + 2)};
+    const V3 v = hull_support(b, neg(n));
+    const double ds = dot(sub(v, pp), n);
+    if (!(ds > margin)) {
+      hit = true; dist = ds; nrm = n;
+      pos = {v.x - 0.5 * ds * n.x, v.y - 0.5 * ds * n.y, v.z - 0.5 * ds * n.z};
+    }
+  } else {
+    CObj a;
+    const int mesh = cm.geom_dataid[g1];
+    a.vertadr = cm.mesh_vertadr[mesh];
+    a.vert = cm.hull_vert + 3 * (size_t)a.vertadr;
+    a.adj_start = cm.hull_adj_start; a.adj = cm.hull_adj; a.cache = 0;
+    a.xpos = {AT(c.geom_xpos, 3 * g1), AT(c.geom_xpos, 3 * g1 + 1), AT(c.geom_xpos, 3 * g1 + 2)};
+    for (int k = 0; k < 9; k++) a.R.a[k] = AT(c.geom_xmat, 9 * g1 + k);
+    a.margin = 0.5 * margin; b.margin = 0.5 * margin;
+    double depth;
+    int iters = 0;
+    if (mpr_penetration(a, b, cm.mpr_tolerance, cm.mpr_iterations, depth, nrm, pos, iters)) {
+      if (!(nrm.x == 0 && nrm.y == 0 && nrm.z == 0)) { hit = true; dist = margin - depth; }
+    }
+    if (c.stat) { atomicAdd(c.stat, 1ull); atomicAdd(c.stat + 1, (unsigned long long)iters); }
+  }
+  AT(c.cand_hit, slot) = hit ? 1 : 0;
+  if (hit) {
+    AT(c.cand_dist, slot) = dist;
+    AT(c.cand_pos, 3 * slot) = pos.x; AT(c.cand_pos, 3 * slot + 1) = pos.y; AT(c.cand_pos, 3 * slot + 2) = pos.z;
+    AT(c.cand_nrm, 3 * slot) = nrm.x; AT(c.cand_nrm, 3 * slot + 1) = nrm.y; AT(c.cand_nrm, 3 * slot + 2) = nrm.z;
+  }
+}
+
+// contact assembly: hits in candidate order -> contact list with completed tangent frames
+__device__ inline void col_assemble(const ColModel& cm, const DevData& d, const ColData& c, long e) {
+  const long E = d.E;
+  const int nc = AT(c.ncand, 0);
+  int n = 0;
+  for (int s = 0; s < nc; s++) {
+    if (!AT(c.cand_hit, s)) continue;
+    if (n >= cm.maxcon) { AT(d.warning, 0) |= 8; break; }
+    AT(c.con_pair, n) = AT(c.cand_pair, s);
+    AT(c.con_dist, n) = AT(c.cand_dist, s);
+    for (int k = 0; k < 3; k++) AT(c.con_pos, 3 * n + k) = AT(c.cand_pos, 3 * s + k);
+    V3 x = normalized(V3{AT(c.cand_nrm, 3 * s), AT(c.cand_nrm, 3 * s + 1), AT(c.cand_nrm, 3 * s + 2)});
+    V3 y = {0, 0, 0};
+    if (x.y < 0.5 && x.y > -0.5) y.y = 1;
+    else y.z = 1;
+    const double t = dot(x, y);
+    y = normalized(V3{y.x - t * x.x, y.y - t * x.y, y.z - t * x.z});
+    const V3 z = cross(x, y);
+    AT(c.con_frame, 9 * n) = x.x; AT(c.con_frame, 9 * n + 1) = x.y; AT(c.con_frame, 9 * n + 2) = x.z;
+    AT(c.con_frame, 9 * n + 3) = y.x; AT(c.con_frame, 9 * n + 4) = y.y; AT(c.con_frame, 9 * n + 5) = y.z;
+    AT(c.con_frame, 9 * n + 6) = z.x; AT(c.con_frame, 9 * n + 7) = z.y; AT(c.con_frame, 9 * n + 8) = z.z;
+    n++;
+  }
+  AT(c.ncon, 0) = n;
+  if (c.stat && n) atomicAdd(c.stat + 2, (unsigned long long)n);
+}

@@ -27,7 +27,7 @@ _SHAPES = {
     "cinert": lambda m: (m.nbody, 10), "crb": lambda m: (m.nbody, 10), "cdof": lambda m: (m.nv, 6),
     "cvel": lambda m: (m.nbody, 6), "rootcom": lambda m: (m.nbody, 3),
 }
-_SCALARS = ("time", "solver_iter", "warning", "nefc")
+_SCALARS = ("time", "solver_iter", "warning", "nefc", "ncon")
 
 
 class _DevArray:
@@ -82,7 +82,7 @@ class BatchData:
         rows, n = int(shape[0]), int(shape[1])
         esz = 4 if is_int.value else 8
         if rows == 0 or ptr.value is None:
-            t = torch.zeros((n, 0), dtype=torch.int32 if is_int.value else torch.float64,
+            t = torch.zeros((n, 1 if name in _SCALARS else 0), dtype=torch.int32 if is_int.value else torch.float64,
                             device=f"cuda:{sim.device_id}")
         else:
             arr = _DevArray(ptr.value, (rows, n), (int(stride[0]) * esz, int(stride[1]) * esz),
@@ -101,9 +101,6 @@ class BatchData:
     def __getattr__(self, name):
         if name in _abi.FIELD_ID:
             return self._view(name)
-        if name == "ncon":
-            import torch
-            return torch.zeros(self._sim.n_envs, dtype=torch.int32, device=f"cuda:{self._sim.device_id}")
         if name == "subtree_com":
             return self._view("rootcom")
         raise AttributeError(name)
@@ -114,6 +111,15 @@ class BatchData:
             self._view(name).copy_(torch.as_tensor(value))
         else:
             raise AttributeError(f"cannot set {name}")
+
+    def contacts(self, env=0, cap=64):
+        """`sim.data.contact[i].geom1/geom2/dist` for one environment: list of (geom1, geom2, dist)."""
+        g1 = (C.c_int32 * cap)()
+        g2 = (C.c_int32 * cap)()
+        dist = (C.c_double * cap)()
+        n = C.c_int()
+        _abi.check(_abi.lib().bs_get_contacts(self._sim._h, int(env), g1, g2, dist, cap, C.byref(n)))
+        return [(g1[i], g2[i], dist[i]) for i in range(min(n.value, cap))]
 
     def to_host(self, name):
         """Dense NumPy copy `[rows, n_envs]` of a field via bs_copy_field (synchronises)."""
@@ -213,6 +219,11 @@ class BatchSim:
         ms = (C.c_double * 5)()
         _abi.check(_abi.lib().bs_stage_times(self._h, ms, 5))
         return dict(position=ms[0], collision=ms[1], velocity=ms[2], constraint=ms[3], integrate=ms[4])
+
+    def collision_stats(self, reset=False):
+        out = (C.c_uint64 * 3)()
+        _abi.check(_abi.lib().bs_collision_stats(self._h, out, 1 if reset else 0))
+        return dict(narrow_pairs=int(out[0]), mpr_iterations=int(out[1]), contacts=int(out[2]))
 
     def timed_steps(self, n):
         ms = C.c_double()

@@ -1,13 +1,395 @@
-/* oracle_collide.c — collision stage of the CPU restatement (A5/A6). TEST INFRASTRUCTURE ONLY.
- * Placeholder until the narrowphase lands: contacts disabled => ncon = 0. */
+/* oracle_collide.c — collision stage of the CPU restatement.
+ * TEST INFRASTRUCTURE ONLY; PARITY UNPINNED (see oracle.h).
+ *
+ * Restates, from published descriptions [EXT], what MuJoCo 2.1.0 does for the exporter's geoms
+ * (type="mesh", margin 0.0005, contype=conaffinity=1: reference src/Mujoco_XML.py:70; excludes
+ * src/Mujoco_XML.py:218-219,267 / output/DexterousDynamos.xml:138-159):
+ *   - candidate pairs were filtered at compile time (mujoco_amd/model.py::_build_pairs);
+ *   - broadphase: bounding spheres about the geom centre, inflated by the pair margin;
+ *   - mesh-mesh narrowphase (mjc_Convex): Minkowski Portal Refinement (libccd's
+ *     ccdMPRPenetration, XenoCollide) on the convex hulls, each hull inflated by margin/2,
+ *     support by steepest-ascent hill climbing over the hull's vertex graph; at most ONE contact
+ *     per pair; dist = margin - depth, position = MPR's barycentric estimate;
+ *   - plane-mesh (the build's own ground plane): deepest hull vertex;
+ *   - contact parameters: friction/condim = max over the geoms, solref/solimp mixed by solmix,
+ *     margin/gap = max; tangent frame completed as mju_makeFrame does.
+ */
 #include "oracle.h"
 
-void orc_collision(const orc_model *m, orc_data *d) {
-  (void)m;
-  d->ncon = 0;
+#include <float.h>
+#include <math.h>
+#include <string.h>
+
+enum { GEOM_PLANE = 0, GEOM_MESH = 7 };
+enum { DSBL_CONTACT = 1 << 4 };
+
+#define CCD_EPS DBL_EPSILON
+static int is_zero(double x) { return fabs(x) < CCD_EPS; }
+static int is_eq(double a, double b) {
+  double ab = fabs(a - b);
+  if (ab < CCD_EPS) return 1;
+  double aa = fabs(a), bb = fabs(b);
+  return ab < CCD_EPS * (bb > aa ? bb : aa);
 }
-int orc_narrow_pair(const orc_model *m, const orc_data *d, int g1, int g2, double margin,
-                    double *dist, double *pos, double *normal) {
-  (void)m; (void)d; (void)g1; (void)g2; (void)margin; (void)dist; (void)pos; (void)normal;
+static double dot3(const double *a, const double *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+static void cross3(double *r, const double *a, const double *b) {
+  double t[3] = {a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]};
+  memcpy(r, t, sizeof t);
+}
+static void sub3(double *r, const double *a, const double *b) { r[0] = a[0] - b[0]; r[1] = a[1] - b[1]; r[2] = a[2] - b[2]; }
+static double norm3(const double *a) { return sqrt(dot3(a, a)); }
+static void normalize3(double *a) {
+  double n = norm3(a);
+  if (n > 0) { a[0] /= n; a[1] /= n; a[2] /= n; }
+}
+static int vec_eq(const double *a, const double *b) { return is_eq(a[0], b[0]) && is_eq(a[1], b[1]) && is_eq(a[2], b[2]); }
+
+/* one convex object: a mesh geom's hull in world pose, inflated by `margin` */
+typedef struct {
+  const double *vert;           /* hull vertices of the mesh (local) */
+  const int32_t *adj_start, *adj; /* CSR adjacency: adj_start is absolute per global vertex */
+  int nvert, vertadr;
+  const double *xpos, *xmat;
+  double margin;
+  int cache;                    /* last support vertex (hill-climb warm start) */
+} cobj;
+
+typedef struct { double v[3], v1[3], v2[3]; } spt; /* Minkowski-difference support point */
+
+/* support of the inflated hull in world direction dir (unit length) */
+static void hull_support(cobj *o, const double *dir, double *res) {
+  const double *R = o->xmat;
+  double d[3] = {R[0] * dir[0] + R[3] * dir[1] + R[6] * dir[2], R[1] * dir[0] + R[4] * dir[1] + R[7] * dir[2],
+                 R[2] * dir[0] + R[5] * dir[1] + R[8] * dir[2]};
+  int imax = o->cache, prev = -1;
+  double vmax = dot3(o->vert + 3 * imax, d);
+  while (imax != prev) {
+    prev = imax;
+    int g = o->vertadr + prev;
+    for (int k = o->adj_start[g]; k < o->adj_start[g + 1]; k++) {
+      int nb = o->adj[k];
+      double val = dot3(o->vert + 3 * nb, d);
+      if (val > vmax) { vmax = val; imax = nb; }
+    }
+  }
+  o->cache = imax;
+  const double *v = o->vert + 3 * imax;
+  for (int r = 0; r < 3; r++)
+    res[r] = o->xpos[r] + R[3 * r] * v[0] + R[3 * r + 1] * v[1] + R[3 * r + 2] * v[2] + o->margin * dir[r];
+}
+
+static void md_support(cobj *a, cobj *b, const double *dir, spt *s) {
+  double nd[3] = {-dir[0], -dir[1], -dir[2]};
+  hull_support(a, dir, s->v1);
+  hull_support(b, nd, s->v2);
+  sub3(s->v, s->v1, s->v2);
+}
+
+/* ---- Minkowski Portal Refinement (XenoCollide), following libccd's control flow */
+typedef struct { spt p[4]; int size; } portal_t;
+
+static void portal_dir(const portal_t *P, double *dir) {
+  double a[3], b[3];
+  sub3(a, P->p[2].v, P->p[1].v);
+  sub3(b, P->p[3].v, P->p[1].v);
+  cross3(dir, a, b);
+  normalize3(dir);
+}
+static int reach_tolerance(const portal_t *P, const spt *v4, const double *dir, double tol) {
+  double dv4 = dot3(v4->v, dir);
+  double d1 = dv4 - dot3(P->p[1].v, dir), d2 = dv4 - dot3(P->p[2].v, dir), d3 = dv4 - dot3(P->p[3].v, dir);
+  double m = d1 < d2 ? d1 : d2;
+  m = m < d3 ? m : d3;
+  return is_eq(m, tol) || m < tol;
+}
+static void expand_portal(portal_t *P, const spt *v4) {
+  double v4v0[3];
+  cross3(v4v0, v4->v, P->p[0].v);
+  if (dot3(P->p[1].v, v4v0) > 0) {
+    if (dot3(P->p[2].v, v4v0) > 0) P->p[1] = *v4;
+    else P->p[3] = *v4;
+  } else {
+    if (dot3(P->p[3].v, v4v0) > 0) P->p[2] = *v4;
+    else P->p[1] = *v4;
+  }
+}
+static int discover_portal(cobj *a, cobj *b, portal_t *P) {
+  double dir[3], va[3], vb[3], d;
+  memcpy(P->p[0].v1, a->xpos, 24);
+  memcpy(P->p[0].v2, b->xpos, 24);
+  sub3(P->p[0].v, P->p[0].v1, P->p[0].v2);
+  P->size = 1;
+  const double origin[3] = {0, 0, 0};
+  if (vec_eq(P->p[0].v, origin)) { P->p[0].v[0] = CCD_EPS * 10; P->p[0].v[1] = P->p[0].v[2] = 0; }
+  dir[0] = -P->p[0].v[0]; dir[1] = -P->p[0].v[1]; dir[2] = -P->p[0].v[2];
+  normalize3(dir);
+  md_support(a, b, dir, &P->p[1]);
+  P->size = 2;
+  d = dot3(P->p[1].v, dir);
+  if (is_zero(d) || d < 0) return -1;
+  cross3(dir, P->p[0].v, P->p[1].v);
+  if (is_zero(dot3(dir, dir))) return vec_eq(P->p[1].v, origin) ? 1 : 2;
+  normalize3(dir);
+  md_support(a, b, dir, &P->p[2]);
+  d = dot3(P->p[2].v, dir);
+  if (is_zero(d) || d < 0) return -1;
+  P->size = 3;
+  sub3(va, P->p[1].v, P->p[0].v);
+  sub3(vb, P->p[2].v, P->p[0].v);
+  cross3(dir, va, vb);
+  normalize3(dir);
+  if (dot3(dir, P->p[0].v) > 0) {
+    spt t = P->p[1]; P->p[1] = P->p[2]; P->p[2] = t;
+    dir[0] = -dir[0]; dir[1] = -dir[1]; dir[2] = -dir[2];
+  }
+  int guard = 0;
+  while (P->size < 4) {
+    if (++guard > 100) return -1;
+    md_support(a, b, dir, &P->p[3]);
+    d = dot3(P->p[3].v, dir);
+    if (is_zero(d) || d < 0) return -1;
+    int cont = 0;
+    cross3(va, P->p[1].v, P->p[3].v);
+    d = dot3(va, P->p[0].v);
+    if (d < 0 && !is_zero(d)) { P->p[2] = P->p[3]; cont = 1; }
+    if (!cont) {
+      cross3(va, P->p[3].v, P->p[2].v);
+      d = dot3(va, P->p[0].v);
+      if (d < 0 && !is_zero(d)) { P->p[1] = P->p[3]; cont = 1; }
+    }
+    if (cont) {
+      sub3(va, P->p[1].v, P->p[0].v);
+      sub3(vb, P->p[2].v, P->p[0].v);
+      cross3(dir, va, vb);
+      normalize3(dir);
+    } else P->size = 4;
+  }
   return 0;
+}
+static int refine_portal(cobj *a, cobj *b, portal_t *P, double tol, int maxit, int64_t *iters) {
+  double dir[3];
+  spt v4;
+  for (int it = 0; it <= maxit + 1; it++) {
+    portal_dir(P, dir);
+    double d = dot3(dir, P->p[1].v);
+    if (is_zero(d) || d > 0) return 0; /* portal encapsulates the origin */
+    md_support(a, b, dir, &v4);
+    (*iters)++;
+    d = dot3(v4.v, dir);
+    if (!(is_zero(d) || d > 0) || reach_tolerance(P, &v4, dir, tol)) return -1;
+    expand_portal(P, &v4);
+  }
+  return -1;
+}
+/* squared distance from the origin to triangle (a,b,c) and the closest point */
+static double origin_tri_dist2(const double *a, const double *b, const double *c, double *w) {
+  double ab[3], ac[3], ap[3] = {-a[0], -a[1], -a[2]};
+  sub3(ab, b, a);
+  sub3(ac, c, a);
+  double d1 = dot3(ab, ap), d2 = dot3(ac, ap);
+  if (d1 <= 0 && d2 <= 0) { memcpy(w, a, 24); return dot3(w, w); }
+  double bp[3] = {-b[0], -b[1], -b[2]};
+  double d3 = dot3(ab, bp), d4 = dot3(ac, bp);
+  if (d3 >= 0 && d4 <= d3) { memcpy(w, b, 24); return dot3(w, w); }
+  double vc = d1 * d4 - d3 * d2;
+  if (vc <= 0 && d1 >= 0 && d3 <= 0) {
+    double v = d1 / (d1 - d3);
+    for (int k = 0; k < 3; k++) w[k] = a[k] + v * ab[k];
+    return dot3(w, w);
+  }
+  double cp[3] = {-c[0], -c[1], -c[2]};
+  double d5 = dot3(ab, cp), d6 = dot3(ac, cp);
+  if (d6 >= 0 && d5 <= d6) { memcpy(w, c, 24); return dot3(w, w); }
+  double vb = d5 * d2 - d1 * d6;
+  if (vb <= 0 && d2 >= 0 && d6 <= 0) {
+    double v = d2 / (d2 - d6);
+    for (int k = 0; k < 3; k++) w[k] = a[k] + v * ac[k];
+    return dot3(w, w);
+  }
+  double va = d3 * d6 - d5 * d4;
+  if (va <= 0 && (d4 - d3) >= 0 && (d5 - d6) >= 0) {
+    double v = (d4 - d3) / ((d4 - d3) + (d5 - d6));
+    for (int k = 0; k < 3; k++) w[k] = b[k] + v * (c[k] - b[k]);
+    return dot3(w, w);
+  }
+  double den = 1.0 / (va + vb + vc), v = vb * den, u = vc * den;
+  for (int k = 0; k < 3; k++) w[k] = a[k] + ab[k] * v + ac[k] * u;
+  return dot3(w, w);
+}
+static void find_pos(const portal_t *P, double *pos) {
+  double dir[3], t[3], bb[4], sum;
+  portal_dir(P, dir);
+  cross3(t, P->p[1].v, P->p[2].v); bb[0] = dot3(t, P->p[3].v);
+  cross3(t, P->p[3].v, P->p[2].v); bb[1] = dot3(t, P->p[0].v);
+  cross3(t, P->p[0].v, P->p[1].v); bb[2] = dot3(t, P->p[3].v);
+  cross3(t, P->p[2].v, P->p[1].v); bb[3] = dot3(t, P->p[0].v);
+  sum = bb[0] + bb[1] + bb[2] + bb[3];
+  if (is_zero(sum) || sum < 0) {
+    bb[0] = 0;
+    cross3(t, P->p[2].v, P->p[3].v); bb[1] = dot3(t, dir);
+    cross3(t, P->p[3].v, P->p[1].v); bb[2] = dot3(t, dir);
+    cross3(t, P->p[1].v, P->p[2].v); bb[3] = dot3(t, dir);
+    sum = bb[1] + bb[2] + bb[3];
+  }
+  double inv = 1.0 / sum;
+  for (int k = 0; k < 3; k++) {
+    double p1 = 0, p2 = 0;
+    for (int i = 0; i < 4; i++) { p1 += bb[i] * P->p[i].v1[k]; p2 += bb[i] * P->p[i].v2[k]; }
+    pos[k] = 0.5 * (p1 * inv + p2 * inv);
+  }
+}
+/* returns 0 when the inflated hulls intersect: depth, unit direction (obj1 -> obj2), position */
+static int mpr_penetration(cobj *a, cobj *b, double tol, int maxit, double *depth, double *dir, double *pos,
+                           int64_t *iters) {
+  portal_t P;
+  int res = discover_portal(a, b, &P);
+  if (res < 0) return -1;
+  if (res == 1) { /* touching contact: no direction */
+    *depth = 0; dir[0] = dir[1] = dir[2] = 0;
+    for (int k = 0; k < 3; k++) pos[k] = 0.5 * (P.p[1].v1[k] + P.p[1].v2[k]);
+    return 0;
+  }
+  if (res == 2) { /* origin on the segment v0-v1 */
+    *depth = norm3(P.p[1].v);
+    memcpy(dir, P.p[1].v, 24);
+    normalize3(dir);
+    for (int k = 0; k < 3; k++) pos[k] = 0.5 * (P.p[1].v1[k] + P.p[1].v2[k]);
+    return 0;
+  }
+  if (refine_portal(a, b, &P, tol, maxit, iters) < 0) return -1;
+  int it = 0;
+  for (;;) {
+    double d[3];
+    spt v4;
+    portal_dir(&P, d);
+    md_support(a, b, d, &v4);
+    (*iters)++;
+    if (reach_tolerance(&P, &v4, d, tol) || it > maxit) {
+      double w[3];
+      *depth = sqrt(origin_tri_dist2(P.p[1].v, P.p[2].v, P.p[3].v, w));
+      if (is_zero(*depth)) dir[0] = dir[1] = dir[2] = 0;
+      else { memcpy(dir, w, 24); normalize3(dir); }
+      find_pos(&P, pos);
+      return 0;
+    }
+    expand_portal(&P, &v4);
+    it++;
+  }
+}
+
+static void make_cobj(const orc_model *m, const orc_data *d, int g, double margin, cobj *o) {
+  int mesh = m->geom_dataid[g];
+  o->vertadr = m->mesh_vertadr[mesh];
+  o->nvert = m->mesh_vertnum[mesh];
+  o->vert = m->hull_vert + 3 * (size_t)o->vertadr;
+  o->adj_start = m->hull_adj_start;
+  o->adj = m->hull_adj;
+  o->xpos = d->geom_xpos + 3 * g;
+  o->xmat = d->geom_xmat + 9 * g;
+  o->margin = margin;
+  o->cache = 0;
+}
+
+/* mju_makeFrame: complete a right-handed frame from its (unit) first axis */
+static void make_frame(double *f) {
+  double *x = f, *y = f + 3, *z = f + 6;
+  normalize3(x);
+  y[0] = y[1] = y[2] = 0;
+  if (x[1] < 0.5 && x[1] > -0.5) y[1] = 1;
+  else y[2] = 1;
+  double t = dot3(x, y);
+  for (int k = 0; k < 3; k++) y[k] -= t * x[k];
+  normalize3(y);
+  cross3(z, x, y);
+}
+
+/* mesh-mesh: 1 contact or none.  `dist`, `pos`, `normal` as MuJoCo's mjContact fields */
+static int convex_pair(const orc_model *m, const orc_data *d, int g1, int g2, double margin, double *dist,
+                       double *pos, double *normal, int64_t *iters) {
+  cobj a, b;
+  make_cobj(m, d, g1, 0.5 * margin, &a);
+  make_cobj(m, d, g2, 0.5 * margin, &b);
+  double depth, dir[3];
+  if (mpr_penetration(&a, &b, m->mpr_tolerance, m->mpr_iterations, &depth, dir, pos, iters) != 0) return 0;
+  if (dir[0] == 0 && dir[1] == 0 && dir[2] == 0) return 0;
+  *dist = margin - depth;
+  memcpy(normal, dir, 24);
+  return 1;
+}
+/* plane (g1) - mesh (g2): the deepest hull vertex, contact at the midpoint */
+static int plane_pair(const orc_model *m, const orc_data *d, int g1, int g2, double margin, double *dist,
+                      double *pos, double *normal) {
+  cobj b;
+  make_cobj(m, d, g2, 0.0, &b);
+  const double *pm = d->geom_xmat + 9 * g1, *pp = d->geom_xpos + 3 * g1;
+  double n[3] = {pm[2], pm[5], pm[8]}, nd[3] = {-pm[2], -pm[5], -pm[8]}, v[3], df[3];
+  hull_support(&b, nd, v);
+  sub3(df, v, pp);
+  double ds = dot3(df, n);
+  if (ds > margin) return 0;
+  *dist = ds;
+  for (int k = 0; k < 3; k++) pos[k] = v[k] - 0.5 * ds * n[k];
+  memcpy(normal, n, 24);
+  return 1;
+}
+
+int orc_narrow_pair(const orc_model *m, const orc_data *d, int g1, int g2, double margin, double *dist,
+                    double *pos, double *normal) {
+  int64_t it = 0;
+  if (m->geom_type[g1] == GEOM_PLANE && m->geom_type[g2] == GEOM_MESH)
+    return plane_pair(m, d, g1, g2, margin, dist, pos, normal);
+  if (m->geom_type[g1] == GEOM_MESH && m->geom_type[g2] == GEOM_MESH)
+    return convex_pair(m, d, g1, g2, margin, dist, pos, normal, &it);
+  return 0;
+}
+
+void orc_collision(const orc_model *m, orc_data *d) {
+  d->ncon = 0;
+  if (m->disableflags & DSBL_CONTACT) return;
+  for (int p = 0; p < m->npair; p++) {
+    int g1 = m->pair_geom1[p], g2 = m->pair_geom2[p];
+    double margin = fmax(m->geom_margin[g1], m->geom_margin[g2]);
+    double gap = fmax(m->geom_gap[g1], m->geom_gap[g2]);
+    int t1 = m->geom_type[g1], t2 = m->geom_type[g2];
+    /* broadphase: bounding spheres (a plane has rbound 0: sphere-plane test instead) */
+    if (m->geom_rbound[g1] > 0 && m->geom_rbound[g2] > 0) {
+      double df[3];
+      sub3(df, d->geom_xpos + 3 * g1, d->geom_xpos + 3 * g2);
+      if (norm3(df) > margin + m->geom_rbound[g1] + m->geom_rbound[g2]) continue;
+    } else if (t1 == GEOM_PLANE && m->geom_rbound[g2] > 0) {
+      const double *pm = d->geom_xmat + 9 * g1;
+      double n[3] = {pm[2], pm[5], pm[8]}, df[3];
+      sub3(df, d->geom_xpos + 3 * g2, d->geom_xpos + 3 * g1);
+      if (dot3(df, n) > margin + m->geom_rbound[g2]) continue;
+    }
+    double dist, pos[3], nrm[3];
+    int hit;
+    if (t1 == GEOM_PLANE && t2 == GEOM_MESH) hit = plane_pair(m, d, g1, g2, margin, &dist, pos, nrm);
+    else if (t1 == GEOM_MESH && t2 == GEOM_MESH) {
+      d->stat_npair_narrow++;
+      hit = convex_pair(m, d, g1, g2, margin, &dist, pos, nrm, &d->stat_mpr_iter);
+    } else continue; /* other geom types are outside the exporter's dialect */
+    if (!hit) continue;
+    if (d->ncon >= ORC_MAXCON) { d->warning |= 8; break; }
+    orc_contact *c = d->contact + d->ncon++;
+    memset(c, 0, sizeof *c);
+    c->dist = dist;
+    memcpy(c->pos, pos, 24);
+    memcpy(c->frame, nrm, 24);
+    make_frame(c->frame);
+    c->includemargin = margin - gap;
+    c->geom1 = g1; c->geom2 = g2;
+    c->dim = m->geom_condim[g1] > m->geom_condim[g2] ? m->geom_condim[g1] : m->geom_condim[g2];
+    const double *f1 = m->geom_friction + 3 * g1, *f2 = m->geom_friction + 3 * g2;
+    double fr[3];
+    for (int k = 0; k < 3; k++) fr[k] = fmax(f1[k], f2[k]);
+    c->friction[0] = c->friction[1] = fr[0]; c->friction[2] = fr[1]; c->friction[3] = c->friction[4] = fr[2];
+    double s1 = m->geom_solmix[g1], s2 = m->geom_solmix[g2], mix;
+    if (s1 >= 1e-15 && s2 >= 1e-15) mix = s1 / (s1 + s2);
+    else if (s1 < 1e-15 && s2 < 1e-15) mix = 0.5;
+    else mix = s1 < 1e-15 ? 0.0 : 1.0;
+    for (int k = 0; k < 2; k++) c->solref[k] = mix * m->geom_solref[2 * g1 + k] + (1 - mix) * m->geom_solref[2 * g2 + k];
+    for (int k = 0; k < 5; k++) c->solimp[k] = mix * m->geom_solimp[5 * g1 + k] + (1 - mix) * m->geom_solimp[5 * g2 + k];
+    c->efc_address = -1;
+  }
 }

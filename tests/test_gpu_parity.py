@@ -204,3 +204,103 @@ def test_error_behaviour(hand_model):
     bad.opt_solver = 0
     with pytest.raises(BatchSimError):
         BatchSim(bad, n_envs=1)
+
+
+# ---------------------------------------------------------------------------------------------
+# contacts (BASELINE.json configs[2] shape: mesh self-collision + the build's ground plane)
+def _contact_model(hand_model):
+    return hand_model.copy()
+
+
+def test_contact_sets_exact(hand_model):
+    """Contact sets (geom pair ids) equal the oracle's exactly after sorting; dist/qacc close."""
+    import torch
+    from mujoco_amd import BatchSim, workload
+    m = _contact_model(hand_model)
+    E = 128
+    q, v = workload.config2_state(m, E, seed=1235)
+    c = workload.config2_ctrl(m, E, seed=1235)
+    sim = BatchSim(m, n_envs=E)
+    sim.data.qpos.copy_(torch.as_tensor(q))
+    sim.data.ctrl.copy_(torch.as_tensor(c))
+    sim.forward()
+    sim.sync()
+    ncon = sim.data.ncon.cpu().numpy()
+    qacc = sim.data.qacc.cpu().numpy()
+    nefc = sim.data.nefc.cpu().numpy()
+    assert ncon.sum() > 100  # the workload really has contacts
+    near = 0
+    for e in range(0, E, 3):
+        ref, s = _oracle_forward(m, q[e], v[e] * 0, c[e], ["qacc"])
+        want = sorted((cc["geom1"], cc["geom2"]) for cc in s.contacts())
+        got = sim.data.contacts(e)
+        assert sorted((g1, g2) for g1, g2, _ in got) == want, e
+        assert ncon[e] == s.ncon and nefc[e] == s.nefc
+        dref = {(cc["geom1"], cc["geom2"]): cc["dist"] for cc in s.contacts()}
+        for g1, g2, dist in got:
+            assert abs(dist - dref[(g1, g2)]) < 1e-9
+            near += abs(dist - 0.0005) < 1e-6
+        err = np.abs(qacc[e] - ref["qacc"]).max() / max(1.0, np.abs(ref["qacc"]).max())
+        assert err < 1e-8, (e, err)
+    st = sim.collision_stats()
+    assert st["narrow_pairs"] > 0 and st["contacts"] == int(ncon.sum())
+
+
+def test_contact_trajectory(hand_model):
+    """200 steps with contacts: the trajectory follows the oracle while contact sets agree."""
+    import torch
+    from mujoco_amd import BatchSim, workload
+    from oracle import OracleSim
+    m = _contact_model(hand_model)
+    E = 64
+    q, v = workload.config2_state(m, E, seed=77)
+    c = workload.config2_ctrl(m, E, seed=77)
+    sim = BatchSim(m, n_envs=E)
+    sim.data.qpos.copy_(torch.as_tensor(q))
+    sim.data.ctrl.copy_(torch.as_tensor(c))
+    sim.step(200)
+    sim.sync()
+    qg = sim.data.qpos.cpu().numpy()
+    assert sim.data.warning.cpu().numpy().max() == 0
+    for e in (0, 21, 63):
+        s = OracleSim(m)
+        s.qpos[:] = q[e]
+        s.ctrl[:] = c[e]
+        s.step(200)
+        assert np.abs(qg[e] - s.qpos).max() < 1e-5, e
+
+
+def test_ground_plane_contact(hand_model):
+    """The build's own ground plane (not in the reference XML)."""
+    import torch
+    from mujoco_amd import BatchSim
+    from mujoco_amd.model import GEOM_PLANE
+    from oracle import OracleSim
+    m = hand_model.copy()
+    # append a plane geom on the world body just below the lowest finger pose reach
+    import numpy as np
+    def app(a, v):
+        return np.concatenate([a, np.asarray(v, dtype=a.dtype).reshape((1,) + a.shape[1:])])
+    g = m.ngeom
+    m.geom_type = app(m.geom_type, GEOM_PLANE); m.geom_bodyid = app(m.geom_bodyid, 0)
+    m.geom_dataid = app(m.geom_dataid, -1); m.geom_contype = app(m.geom_contype, 1)
+    m.geom_conaffinity = app(m.geom_conaffinity, 1); m.geom_condim = app(m.geom_condim, 3)
+    m.geom_priority = app(m.geom_priority, 0); m.geom_pos = app(m.geom_pos, [0, 0, -0.06])
+    m.geom_quat = app(m.geom_quat, [1, 0, 0, 0]); m.geom_size = app(m.geom_size, [0, 0, 1])
+    m.geom_friction = app(m.geom_friction, [1, 0.005, 0.0001]); m.geom_margin = app(m.geom_margin, 0.0)
+    m.geom_gap = app(m.geom_gap, 0.0); m.geom_solref = app(m.geom_solref, [0.02, 1])
+    m.geom_solimp = app(m.geom_solimp, [0.9, 0.95, 0.001, 0.5, 2]); m.geom_solmix = app(m.geom_solmix, 1.0)
+    m.geom_rbound = app(m.geom_rbound, 0.0)
+    m.geom_names = m.geom_names + ["ground_plane"]
+    m._build_pairs()
+    assert m.npair > 210
+    sim = BatchSim(m, n_envs=2)
+    s = OracleSim(m)
+    # swing the wrist so the fingers sweep below the plane height
+    qq = np.zeros(m.nq); qq[0] = -1.3
+    sim.data.qpos.copy_(torch.as_tensor(np.stack([qq, qq])))
+    s.qpos[:] = qq
+    sim.forward(); sim.sync(); s.forward()
+    want = sorted((cc["geom1"], cc["geom2"]) for cc in s.contacts())
+    got = sorted((g1, g2) for g1, g2, _ in sim.data.contacts(1))
+    assert got == want
