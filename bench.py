@@ -54,11 +54,13 @@ def cpu_baseline(model, seconds_budget=12.0):
 
 
 def _pool_worker(args):
-    path, seed, n_envs, n_steps = args
+    path, seed, n_envs, n_steps, contacts = args
     sys.path.insert(0, ROOT)
     from mujoco_amd import Model, workload
     from oracle import OracleSim
-    model = workload.contact_free(Model.load(path))
+    model = Model.load(path)
+    if not contacts:
+        model = workload.contact_free(model)
     q, v = workload.config2_state(model, n_envs, seed=seed)
     c = workload.config2_ctrl(model, n_envs, seed=seed)
     t0 = time.perf_counter()
@@ -70,14 +72,14 @@ def _pool_worker(args):
     return n_envs * n_steps, time.perf_counter() - t0
 
 
-def cpu_baseline_allcores(model_path):
+def cpu_baseline_allcores(model_path, contacts=False):
     import multiprocessing as mp
     cores = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16") or 16), 16)
     n_envs, n_steps = 32, 1000
     ctx = mp.get_context("spawn")
     t0 = time.perf_counter()
     with ctx.Pool(cores) as pool:
-        res = pool.map(_pool_worker, [(model_path, 1234 + i, n_envs, n_steps) for i in range(cores)])
+        res = pool.map(_pool_worker, [(model_path, 1234 + i, n_envs, n_steps, contacts) for i in range(cores)])
     wall = time.perf_counter() - t0
     work = sum(r[0] for r in res)
     inner = max(r[1] for r in res)
@@ -93,6 +95,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--envs", type=int, default=4096, help="environments per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--contacts", action="store_true",
+                    help="BASELINE.json configs[2] shape instead of configs[1]: mesh self-collision enabled "
+                         "(use with --envs 65536); not the default bench line")
     args = ap.parse_args()
 
     import torch
@@ -112,7 +117,11 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
 
     model_path = os.path.join(ROOT, "tests", "golden", "dexterous_model.npz")
-    model = workload.contact_free(Model.load(model_path))
+    model = Model.load(model_path)
+    if not args.contacts:
+        model = workload.contact_free(model)
+    global cpu_model_contacts
+    cpu_model_contacts = args.contacts  # noqa: F841 (informational)
     E = args.envs
     seed = 1234 + 1000 * rank
     q, v = workload.config2_state(model, E, seed=seed)
@@ -176,10 +185,21 @@ def main():
         kms.append(ev0.elapsed_time(ev1))
     k_ms = float(np.mean(kms))
     stage = sim.stage_times()
+    cstat = None
+    if args.contacts:
+        sim.collision_stats(reset=True)
+        sim.step(CTRL_PERIOD)
+        st = sim.collision_stats()
+        cstat = {"narrow_pairs_per_env_step": st["narrow_pairs"] / (E * CTRL_PERIOD),
+                 "mpr_iter_per_pair": st["mpr_iterations"] / max(1, st["narrow_pairs"]),
+                 "ncon_per_env_step": st["contacts"] / (E * CTRL_PERIOD)}
 
     if rank == 0:
         value = E * world * args.steps / wall
-        flops_launch = FLOP_PER_ENV_STEP * E * CTRL_PERIOD
+        flop_env_step = FLOP_PER_ENV_STEP
+        if cstat:  # F = 36k + 12k N_np + 6k ncon n_iter
+            flop_env_step += 12e3 * cstat["narrow_pairs_per_env_step"] + 6e3 * cstat["ncon_per_env_step"] * max(iters, 1.0)
+        flops_launch = flop_env_step * E * CTRL_PERIOD
         achieved = flops_launch / (k_ms * 1e-3) / 1e12
         out = {
             "metric": "env-steps/sec", "value": value, "unit": "env-steps/s", "n_gpus": world,
@@ -195,17 +215,22 @@ def main():
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None,
                          "kernel": "k_tp", "launch_ms": k_ms, "env_steps_per_launch": E * CTRL_PERIOD,
-                         "flop_per_env_step": FLOP_PER_ENV_STEP,
+                         "flop_per_env_step": flop_env_step,
                          "note": "fp64 compute-bound path: peak is the MI355X fp64 vector=matrix rate; "
                                  "algorithmic HBM rate would be "
                                  f"{BYTES_PER_ENV_STEP * E * CTRL_PERIOD / (k_ms * 1e-3) / 1e9:.2f} GB/s of 8000"},
             "gpu_event_ms_per_step": gpu_ms / args.steps,
             "stage_ms_one_step": stage,
         }
+        if cstat:
+            out["config"]["workload"] = ("BASELINE.json configs[2] shape: DexterousDynamos.xml with STL-hull mesh "
+                                         "self-collision (no ground plane: the hand cannot reach one), Euler + Newton")
+            out["config"]["collision"] = cstat
+            out["roofline"]["kernel"] = "k_c_pos+k_c_broad+k_c_narrow+k_c_dyn (one step = 4 launches)"
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(model)
             try:
-                out["cpu_baseline_allcores"] = cpu_baseline_allcores(model_path)
+                out["cpu_baseline_allcores"] = cpu_baseline_allcores(model_path, args.contacts)
             except Exception as ex:  # the pool is informational; the single-thread figure is the contract
                 out["cpu_baseline_allcores"] = {"error": repr(ex)}
         print(json.dumps(out), flush=True)

@@ -184,8 +184,8 @@ extern "C" int bs_model_create(const bs_model_desc* desc, bs_model** out) {
     return fail(BS_ERR_INVALID, "bs_model_create: inconsistent sizes (nbody=%d njnt=%d nv=%d nM=%d)", nb,
                 nj, nv, desc->nM);
   if (!(desc->timestep > 0)) return fail(BS_ERR_INVALID, "bs_model_create: timestep must be > 0");
-  if (desc->solver != 2)
-    return fail(BS_ERR_UNSUPPORTED, "bs_model_create: only the Newton solver (2) is implemented, got %d",
+  if (desc->solver != 2 && desc->solver != 0)
+    return fail(BS_ERR_UNSUPPORTED, "bs_model_create: solver %d is not implemented (0 = PGS, 2 = Newton)",
                 desc->solver);
   if (desc->integrator != 0 && desc->integrator != 1)
     return fail(BS_ERR_INVALID, "bs_model_create: integrator must be 0 (Euler) or 1 (RK4)");
@@ -401,7 +401,7 @@ static int model_image(bs_model* m, int device, const DeviceImage** out) {
   dm.nbody = nb; dm.njnt = nj; dm.nv = nv; dm.nu = nu; dm.ngeom = ng; dm.nM = s.nM; dm.npair = s.npair;
   dm.neq = (int)m->eq_dof1.size(); dm.nfric = (int)m->fric_dof.size(); dm.nlim = (int)m->lim_jnt.size();
   dm.nrow = dm.neq + dm.nfric + 2 * dm.nlim;
-  dm.integrator = s.integrator; dm.iterations = s.iterations; dm.ls_iterations = s.ls_iterations;
+  dm.integrator = s.integrator; dm.solver = s.solver; dm.iterations = s.iterations; dm.ls_iterations = s.ls_iterations;
   dm.disableflags = s.disableflags; dm.damped = m->damped; dm.hess_sparse = m->hess_sparse;
   dm.timestep = s.timestep; memcpy(dm.gravity, s.gravity, sizeof dm.gravity);
   dm.tolerance = s.tolerance; dm.ls_tolerance = s.ls_tolerance; dm.impratio = s.impratio;
@@ -534,7 +534,10 @@ __global__ __launch_bounds__(BS_BLOCK) void k_stage(DevModel m, DevData d, int s
       stage_factor(m, d, e);
       break;
     case 2: stage_velocity(m, d, e); break;
-    case 3: stage_constraint(m, d, e); break;
+    case 3:
+      if (m.solver == 0) stage_constraint_pgs(m, d, e);
+      else stage_constraint(m, d, e);
+      break;
     case 4:
       if (env_check(m, d, e, d.qacc, m.nv, 2)) env_forward(m, d, e);
       if (m.integrator == 1) stage_rk4(m, d, e);
@@ -663,7 +666,7 @@ extern "C" int bs_sim_create(const bs_model* const* models, int n_models, const 
   s->cm = img->cm;
   s->cm.maxcon = (opt && opt->max_contacts_per_env > 0) ? opt->max_contacts_per_env : 32;
   s->cm.maxcand = model->d.npair < 256 ? model->d.npair : 256;
-  s->use_tp = !contacts && model->tp_ok && !(kv && strcmp(kv, "serial") == 0);
+  s->use_tp = !contacts && model->d.solver == 2 && model->tp_ok && !(kv && strcmp(kv, "serial") == 0);
   if (kv && strcmp(kv, "tp") == 0 && !model->tp_ok) {
     delete s;
     return fail(BS_ERR_UNSUPPORTED, "BS_KERNEL=tp but the model is not eligible: %s", model->tp_why.c_str());
@@ -698,7 +701,8 @@ extern "C" int bs_sim_create(const bs_model* const* models, int n_models, const 
       {&d.jar, nrow, -1}, {&d.jv, nrow, -1}, {&d.eq_coef, m.neq, -1}, {&d.fric_rf, m.nfric, -1},
       {&d.Ma, nv, -1}, {&d.grad, nv, -1}, {&d.Mgrad, nv, -1}, {&d.search, nv, -1}, {&d.Mv, nv, -1},
       {&d.H, nM, -1}, {&d.Hdinv, nv, -1},
-      {&d.rk_q0, nj, -1}, {&d.rk_v0, nv, -1}, {&d.rk_Fv, 4 * nv, -1}, {&d.rk_Fa, 4 * nv, -1}};
+      {&d.rk_q0, nj, -1}, {&d.rk_v0, nv, -1}, {&d.rk_Fv, 4 * nv, -1}, {&d.rk_Fa, 4 * nv, -1},
+      {&d.pgs_W, m.solver == 0 ? nrow * nv : 0, -1}};
   size_t rows = 0;
   for (auto& sl : slots) rows += (size_t)(sl.rows > 0 ? sl.rows : 1);
   s->derived_rows = (size_t)9 * nb + (size_t)12 * (m.ngeom > 0 ? m.ngeom : 1);
@@ -734,7 +738,7 @@ extern "C" int bs_sim_create(const bs_model* const* models, int n_models, const 
   s->cd.geom_xmat = (double*)s->fields[BS_F_GEOM_XMAT].ptr;
   if (contacts) {
     const size_t mc = (size_t)s->cm.maxcand, mk = (size_t)s->cm.maxcon, nr = 4 * mk, nh = (size_t)nv * (nv + 1) / 2;
-    const size_t drows = mc * 7 + mk * 13 + nr * nv + nr * 5 + nh;
+    const size_t drows = mc * 7 + mk * 13 + nr * nv + nr * 5 + nh + (model->d.solver == 0 ? nr * nv : 0);
     const size_t irows = 1 + mc * 2 + 1 + mk + 1 + mk;
     const size_t bytes = drows * E * sizeof(double) + irows * E * sizeof(int) + 64;
     he = hipMalloc(&s->carena, bytes);
@@ -753,6 +757,7 @@ extern "C" int bs_sim_create(const bs_model* const* models, int n_models, const 
     c.con_dist = take(mk); c.con_pos = take(3 * mk); c.con_frame = take(9 * mk);
     k.cJ = take(nr * nv); k.cD = take(nr); k.caref = take(nr); k.cjar = take(nr); k.cjv = take(nr); k.cforce = take(nr);
     k.Hd = take(nh);
+    k.cW = model->d.solver == 0 ? take(nr * nv) : nullptr;
     int* ip = (int*)dp;
     auto takei = [&](size_t rows_) { int* q = ip; ip += rows_ * (size_t)E; return q; };
     c.ncand = takei(1); c.cand_pair = takei(mc); c.cand_hit = takei(mc);

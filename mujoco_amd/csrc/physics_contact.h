@@ -14,6 +14,7 @@ struct ConData {
   double *cJ;      // [(row*nv + dof)][E]
   double *cD, *caref, *cjar, *cjv, *cforce;
   double *Hd;      // dense lower-triangular Hessian [(nv*(nv+1)/2)][E]
+  double *cW;      // PGS only: rows of J_c M^-1, [(row*nv + dof)][E]
   int *ncrow;      // [1][E] contact rows of this env
   int *con_efc;    // [maxcon][E] first row of each contact or -1
 };
@@ -285,6 +286,8 @@ __device__ inline double line_search_c(const DevModel& m, const DevData& d, cons
   return best.cost < p0.cost ? best.alpha : 0.0;
 }
 
+__device__ inline void stage_pgs(const DevModel& m, const DevData& d, const ConData* kp, long e, int ncrow);
+
 // A7 + A11 with contacts
 __device__ inline void stage_constraint_c(const DevModel& m, const ColModel& cm, const DevData& d, const ColData& c,
                                           const ConData& k, long e) {
@@ -301,6 +304,10 @@ __device__ inline void stage_constraint_c(const DevModel& m, const ColModel& cm,
       AT(d.qacc, i) = a; AT(d.qacc_warmstart, i) = a; AT(d.qfrc_constraint, i) = 0;
     }
     AT(d.solver_iter, 0) = 0;
+    return;
+  }
+  if (m.solver == 0) {
+    stage_pgs(m, d, &k, e, ncrow);
     return;
   }
   bool use_smooth = true;
@@ -345,4 +352,172 @@ __device__ inline void stage_constraint_c(const DevModel& m, const ColModel& cm,
   }
   AT(d.solver_iter, 0) = iter;
   for (int i = 0; i < m.nv; i++) AT(d.qacc_warmstart, i) = AT(d.qacc, i);
+}
+
+
+// ------------------------------------------------------------------ A11 mj_solPGS (matrix-free)
+// Projected Gauss-Seidel on the dual.  Instead of the dense nefc x nefc matrix A + R the kernel
+// keeps w_i = M^-1 J_i^T per row and the running acceleration a = qacc_smooth + sum_j f_j w_j, so
+// the row residual is  J_i a - aref_i + R_i f_i  and a force change costs one axpy of length nv.
+// Same iteration as mj_solPGS (row order: equality, friction loss, limits, contacts).
+__device__ inline double frow_dot(const DevModel& m, const DevData& d, long e, int r, const double* v) {
+  const long E = d.E;
+  if (r < m.neq) {
+    double s = AT(v, m.eq_dof1[r]);
+    if (m.eq_dof2[r] >= 0) s -= AT(d.eq_coef, r) * AT(v, m.eq_dof2[r]);
+    return s;
+  }
+  if (r < m.neq + m.nfric) return AT(v, m.fric_dof[r - m.neq]);
+  const int q = r - m.neq - m.nfric;
+  const double s = AT(v, m.jnt_dofadr[m.lim_jnt[q >> 1]]);
+  return (q & 1) ? -s : s;
+}
+__device__ inline void frow_scatter(const DevModel& m, const DevData& d, long e, int r, double* v, double f) {
+  const long E = d.E;  // v += f * J_r^T
+  if (r < m.neq) {
+    AT(v, m.eq_dof1[r]) += f;
+    if (m.eq_dof2[r] >= 0) AT(v, m.eq_dof2[r]) -= AT(d.eq_coef, r) * f;
+  } else if (r < m.neq + m.nfric) AT(v, m.fric_dof[r - m.neq]) += f;
+  else {
+    const int q = r - m.neq - m.nfric;
+    AT(v, m.jnt_dofadr[m.lim_jnt[q >> 1]]) += (q & 1) ? -f : f;
+  }
+}
+
+__device__ inline void stage_pgs(const DevModel& m, const DevData& d, const ConData* kp, long e, int ncrow) {
+  const long E = d.E;
+  const int nv = m.nv, nrow = m.nrow;
+  const double scale = 1.0 / (m.meaninertia * (nv > 1 ? nv : 1));
+  // w_i = M^-1 J_i^T and diagonal of A + R
+  for (int r = 0; r < nrow; r++) {
+    if (!(AT(d.efc_D, r) > 0)) continue;
+    for (int i = 0; i < nv; i++) AT(d.Mgrad, i) = 0;
+    frow_scatter(m, d, e, r, d.Mgrad, 1.0);
+    solve_sparse(m, d.qLD, d.qLDiagInv, d.Mgrad, E, e);
+    for (int i = 0; i < nv; i++) AT(d.pgs_W, (size_t)r * nv + i) = AT(d.Mgrad, i);
+    AT(d.jv, r) = frow_dot(m, d, e, r, d.Mgrad) + 1.0 / AT(d.efc_D, r);
+  }
+  for (int r = 0; r < ncrow; r++) {
+    for (int i = 0; i < nv; i++) AT(d.Mgrad, i) = AT(kp->cJ, (size_t)r * nv + i);
+    solve_sparse(m, d.qLD, d.qLDiagInv, d.Mgrad, E, e);
+    double s = 0;
+    for (int i = 0; i < nv; i++) {
+      AT(kp->cW, (size_t)r * nv + i) = AT(d.Mgrad, i);
+      s += AT(kp->cJ, (size_t)r * nv + i) * AT(d.Mgrad, i);
+    }
+    AT(kp->cjv, r) = s + 1.0 / AT(kp->cD, r);
+  }
+  // warm start from the previous acceleration's implied forces, kept if the dual cost is <= 0
+  bool zero = true;
+  if (!(m.disableflags & BS_DSBL_WARMSTART)) {
+    rows_residual(m, d, e, d.qacc_warmstart, d.jar, true);
+    rows_update<true>(m, d, e, d.jar);
+    if (ncrow) {
+      crows_residual(m, d, *kp, e, ncrow, d.qacc_warmstart, kp->cjar, true);
+      crows_update<true>(m, d, *kp, e, ncrow, kp->cjar);
+    }
+    for (int i = 0; i < nv; i++) AT(d.Mgrad, i) = AT(d.qfrc_constraint, i);
+    solve_sparse(m, d.qLD, d.qLDiagInv, d.Mgrad, E, e);  // M^-1 J^T f
+    double c = 0;
+    for (int r = 0; r < nrow; r++) {
+      if (!(AT(d.efc_D, r) > 0)) { AT(d.efc_force, r) = 0; continue; }
+      const double f = AT(d.efc_force, r);
+      c += f * (0.5 * (frow_dot(m, d, e, r, d.Mgrad) + f / AT(d.efc_D, r)) +
+                (frow_dot(m, d, e, r, d.qacc_smooth) - AT(d.efc_aref, r)));
+    }
+    for (int r = 0; r < ncrow; r++) {
+      const double f = AT(kp->cforce, r);
+      double Af = 0, Ja = 0;
+      for (int i = 0; i < nv; i++) {
+        const double J = AT(kp->cJ, (size_t)r * nv + i);
+        Af += J * AT(d.Mgrad, i); Ja += J * AT(d.qacc_smooth, i);
+      }
+      c += f * (0.5 * (Af + f / AT(kp->cD, r)) + (Ja - AT(kp->caref, r)));
+    }
+    zero = c > 0;
+    if (!zero)
+      for (int i = 0; i < nv; i++) AT(d.qacc, i) = AT(d.qacc_smooth, i) + AT(d.Mgrad, i);
+  }
+  if (zero) {
+    for (int r = 0; r < nrow; r++) AT(d.efc_force, r) = 0;
+    for (int r = 0; r < ncrow; r++) AT(kp->cforce, r) = 0;
+    for (int i = 0; i < nv; i++) AT(d.qacc, i) = AT(d.qacc_smooth, i);
+  }
+  int iter = 0;
+  while (iter < m.iterations) {
+    double improvement = 0;
+    for (int r = 0; r < nrow; r++) {
+      const double D = AT(d.efc_D, r);
+      if (!(D > 0)) continue;
+      const double old = AT(d.efc_force, r), ARii = AT(d.jv, r);
+      const double res = frow_dot(m, d, e, r, d.qacc) - AT(d.efc_aref, r) + old / D;
+      double f = old - res / ARii;
+      if (r >= m.neq && r < m.neq + m.nfric) {
+        const double fl = m.dof_frictionloss[m.fric_dof[r - m.neq]];
+        f = f < -fl ? -fl : (f > fl ? fl : f);
+      } else if (r >= m.neq + m.nfric) {
+        if (f < 0) f = 0;
+      }
+      double delta = f - old, change = 0.5 * delta * delta * ARii + delta * res;
+      if (change > 1e-10) { f = old; delta = 0; change = 0; }
+      if (delta != 0) {
+        AT(d.efc_force, r) = f;
+        for (int i = 0; i < nv; i++) AT(d.qacc, i) += delta * AT(d.pgs_W, (size_t)r * nv + i);
+      }
+      improvement -= change;
+    }
+    for (int r = 0; r < ncrow; r++) {
+      const double D = AT(kp->cD, r), old = AT(kp->cforce, r), ARii = AT(kp->cjv, r);
+      double Ja = 0;
+      for (int i = 0; i < nv; i++) Ja += AT(kp->cJ, (size_t)r * nv + i) * AT(d.qacc, i);
+      const double res = Ja - AT(kp->caref, r) + old / D;
+      double f = old - res / ARii;
+      if (f < 0) f = 0;
+      double delta = f - old, change = 0.5 * delta * delta * ARii + delta * res;
+      if (change > 1e-10) { f = old; delta = 0; change = 0; }
+      if (delta != 0) {
+        AT(kp->cforce, r) = f;
+        for (int i = 0; i < nv; i++) AT(d.qacc, i) += delta * AT(kp->cW, (size_t)r * nv + i);
+      }
+      improvement -= change;
+    }
+    iter++;
+    if (improvement * scale < m.tolerance) break;
+  }
+  AT(d.solver_iter, 0) = iter;
+  // map back: qfrc_constraint = J^T f, qacc = qacc_smooth + M^-1 qfrc_constraint
+  for (int i = 0; i < nv; i++) AT(d.qfrc_constraint, i) = 0;
+  for (int r = 0; r < nrow; r++) {
+    const double f = AT(d.efc_force, r);
+    if (f != 0) frow_scatter(m, d, e, r, d.qfrc_constraint, f);
+  }
+  for (int r = 0; r < ncrow; r++) {
+    const double f = AT(kp->cforce, r);
+    if (f != 0)
+      for (int i = 0; i < nv; i++) AT(d.qfrc_constraint, i) += AT(kp->cJ, (size_t)r * nv + i) * f;
+  }
+  for (int i = 0; i < nv; i++) AT(d.Mgrad, i) = AT(d.qfrc_constraint, i);
+  solve_sparse(m, d.qLD, d.qLDiagInv, d.Mgrad, E, e);
+  for (int i = 0; i < nv; i++) {
+    const double a = AT(d.qacc_smooth, i) + AT(d.Mgrad, i);
+    AT(d.qacc, i) = a;
+    AT(d.qacc_warmstart, i) = a;
+  }
+}
+
+// contact-free sims with solver = PGS (serial kernels)
+__device__ inline void stage_constraint_pgs(const DevModel& m, const DevData& d, long e) {
+  const long E = d.E;
+  int nact = 0;
+  if (!(m.disableflags & BS_DSBL_CONSTRAINT)) nact = make_rows(m, d, e);
+  AT(d.nefc, 0) = nact;
+  if (nact == 0) {
+    for (int i = 0; i < m.nv; i++) {
+      const double a = AT(d.qacc_smooth, i);
+      AT(d.qacc, i) = a; AT(d.qacc_warmstart, i) = a; AT(d.qfrc_constraint, i) = 0;
+    }
+    AT(d.solver_iter, 0) = 0;
+    return;
+  }
+  stage_pgs(m, d, nullptr, e, 0);
 }

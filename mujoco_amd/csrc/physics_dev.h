@@ -28,7 +28,7 @@ enum {
 struct DevModel {
   int nbody, njnt, nv, nu, ngeom, neq, nM, npair;
   int nfric, nlim, nrow;  // fixed constraint-row layout: neq | nfric | 2*nlim
-  int integrator, iterations, ls_iterations, disableflags, damped, hess_sparse;
+  int integrator, solver, iterations, ls_iterations, disableflags, damped, hess_sparse;
   double timestep, gravity[3], tolerance, ls_tolerance, impratio, meaninertia;
   const int *body_parentid, *body_rootid, *body_jntadr, *body_jntnum, *body_dofadr, *body_dofnum;
   const double *body_pos, *body_quat, *body_ipos, *body_iquat, *body_mass, *body_subtreemass,
@@ -60,6 +60,7 @@ struct DevData {
   double *efc_D, *efc_aref, *efc_force, *jar, *jv, *eq_coef, *fric_rf;
   double *Ma, *grad, *Mgrad, *search, *Mv, *H, *Hdinv;
   double *rk_q0, *rk_v0, *rk_Fv, *rk_Fa;
+  double *pgs_W;  // PGS only: rows of J M^-1 for the fixed rows, [(row*nv + dof)][E]
   int *solver_iter, *warning, *nefc;
 };
 
@@ -770,11 +771,13 @@ __device__ inline void stage_constraint(const DevModel& m, const DevData& d, lon
   for (int i = 0; i < m.nv; i++) AT(d.qacc_warmstart, i) = AT(d.qacc, i);
 }
 
+__device__ inline void stage_constraint_pgs(const DevModel& m, const DevData& d, long e);  // physics_contact.h
 __device__ inline void env_forward(const DevModel& m, const DevData& d, long e) {
   stage_position(m, d, e);
   stage_factor(m, d, e);
   stage_velocity(m, d, e);
-  stage_constraint(m, d, e);
+  if (m.solver == 0) stage_constraint_pgs(m, d, e);
+  else stage_constraint(m, d, e);
 }
 
 // ------------------------------------------------------------------ A12 mj_Euler

@@ -919,6 +919,65 @@ static void sol_newton(const orc_model *m, orc_data *d) {
   d->solver_iter = iter;
 }
 
+
+/* ------------------------------------------------------------------ A11 mj_solPGS
+ * projected Gauss-Seidel on the dual  min 0.5 f'(A+R)f + f'b,  A = J M^-1 J', b = J qacc_smooth - aref,
+ * with the explicit dense matrix (mj_projectConstraint), scalar projections: equality free,
+ * friction loss in [-floss, floss], limits / pyramidal contact edges >= 0 */
+static void sol_pgs(const orc_model *m, orc_data *d) {
+  int nv = m->nv, n = d->nefc;
+  double *AR = (double *)malloc(sizeof(double) * ((size_t)n * n + (size_t)n * nv + 2 * (size_t)n + nv));
+  double *W = AR + (size_t)n * n, *b = W + (size_t)n * nv, *jar = b + n, *tmp = jar + n;
+  double scale = 1.0 / (m->meaninertia * (nv > 1 ? nv : 1));
+  for (int i = 0; i < n; i++) {
+    memcpy(W + (size_t)i * nv, d->efc_J + (size_t)i * nv, sizeof(double) * nv);
+    orc_solve_m(m, d, W + (size_t)i * nv); /* row i of J M^-1 */
+  }
+  for (int i = 0; i < n; i++) {
+    for (int j = 0; j < n; j++) AR[(size_t)i * n + j] = dotn(W + (size_t)i * nv, d->efc_J + (size_t)j * nv, nv);
+    AR[(size_t)i * n + i] += d->efc_R[i];
+    b[i] = dotn(d->efc_J + (size_t)i * nv, d->qacc_smooth, nv) - d->efc_aref[i];
+  }
+  /* warm start: forces implied by the previous acceleration, kept only if the dual cost is < 0 */
+  if (!(m->disableflags & DSBL_WARMSTART)) {
+    for (int i = 0; i < n; i++)
+      jar[i] = dotn(d->efc_J + (size_t)i * nv, d->qacc_warmstart, nv) - d->efc_aref[i];
+    constraint_update(m, d, jar, 1);
+    double c = 0;
+    for (int i = 0; i < n; i++) c += d->efc_force[i] * (0.5 * dotn(AR + (size_t)i * n, d->efc_force, n) + b[i]);
+    if (c > 0) memset(d->efc_force, 0, sizeof(double) * n);
+  } else
+    memset(d->efc_force, 0, sizeof(double) * n);
+  int iter = 0;
+  while (iter < m->iterations) {
+    double improvement = 0;
+    for (int i = 0; i < n; i++) {
+      double res = b[i] + dotn(AR + (size_t)i * n, d->efc_force, n), old = d->efc_force[i];
+      double f = old - res / AR[(size_t)i * n + i];
+      if (d->efc_type[i] == CT_FRICTION_DOF) {
+        double fl = d->efc_frictionloss[i];
+        f = f < -fl ? -fl : (f > fl ? fl : f);
+      } else if (d->efc_type[i] != CT_EQUALITY) {
+        if (f < 0) f = 0;
+      }
+      double delta = f - old, change = 0.5 * delta * delta * AR[(size_t)i * n + i] + delta * res;
+      if (change > 1e-10) { f = old; change = 0; }
+      d->efc_force[i] = f;
+      improvement -= change;
+    }
+    iter++;
+    if (improvement * scale < m->tolerance) break;
+  }
+  d->solver_iter = iter;
+  for (int k = 0; k < nv; k++) tmp[k] = 0;
+  for (int i = 0; i < n; i++)
+    for (int k = 0; k < nv; k++) tmp[k] += d->efc_J[(size_t)i * nv + k] * d->efc_force[i];
+  memcpy(d->qfrc_constraint, tmp, sizeof(double) * nv);
+  orc_solve_m(m, d, tmp);
+  for (int k = 0; k < nv; k++) d->qacc[k] = d->qacc_smooth[k] + tmp[k];
+  free(AR);
+}
+
 void orc_fwd_constraint(const orc_model *m, orc_data *d) {
   int nv = m->nv;
   if (d->nefc == 0) {
@@ -928,13 +987,18 @@ void orc_fwd_constraint(const orc_model *m, orc_data *d) {
     d->solver_iter = 0;
     return;
   }
+  if (m->solver == SOL_PGS) {
+    sol_pgs(m, d);
+    memcpy(d->qacc_warmstart, d->qacc, sizeof(double) * nv);
+    return;
+  }
   /* warm start: keep the previous acceleration only if it is cheaper than qacc_smooth */
   if (!(m->disableflags & DSBL_WARMSTART)) {
     double cw = orc_cost(m, d, d->qacc_warmstart), cs = orc_cost(m, d, d->qacc_smooth);
     memcpy(d->qacc, cw > cs ? d->qacc_smooth : d->qacc_warmstart, sizeof(double) * nv);
   } else
     memcpy(d->qacc, d->qacc_smooth, sizeof(double) * nv);
-  sol_newton(m, d); /* PGS / CG would dispatch here; Newton is the reference default */
+  sol_newton(m, d); /* Newton is the reference default (no <option> in the XML); CG is not restated */
   memcpy(d->qacc_warmstart, d->qacc, sizeof(double) * nv);
 }
 

@@ -36,8 +36,8 @@ def test_model_desc_validation_without_gpu(hand_model):
     from mujoco_amd.sim import NativeModel
     NativeModel(workload.contact_free(hand_model))  # valid
     bad = hand_model.copy()
-    bad.opt_solver = 0
-    with pytest.raises(_abi.BatchSimError, match="Newton"):
+    bad.opt_solver = 1
+    with pytest.raises(_abi.BatchSimError, match="not implemented"):
         NativeModel(bad)
     bad = hand_model.copy()
     bad.dof_parentid = bad.dof_parentid.copy()

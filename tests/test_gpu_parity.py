@@ -201,7 +201,7 @@ def test_error_behaviour(hand_model):
     with pytest.raises(BatchSimError):
         sim.step(-1)
     bad = m.copy()
-    bad.opt_solver = 0
+    bad.opt_solver = 1  # CG is not implemented
     with pytest.raises(BatchSimError):
         BatchSim(bad, n_envs=1)
 
@@ -304,3 +304,31 @@ def test_ground_plane_contact(hand_model):
     want = sorted((cc["geom1"], cc["geom2"]) for cc in s.contacts())
     got = sorted((g1, g2) for g1, g2, _ in sim.data.contacts(1))
     assert got == want
+
+
+@pytest.mark.parametrize("contacts", [False, True])
+def test_pgs_matches_oracle(hand_model, contacts):
+    """solver=PGS (north_star; BASELINE.json configs[3] 'PGS vs Newton'): device matrix-free PGS vs
+    the oracle's explicit-dual PGS, and both near the Newton fixed point."""
+    import torch
+    from mujoco_amd import BatchSim, workload
+    m = hand_model.copy() if contacts else workload.contact_free(hand_model)
+    m.opt_solver = 0
+    E = 64
+    q, v = workload.config2_state(m, E, seed=1235)
+    c = workload.config2_ctrl(m, E, seed=1235)
+    sim = BatchSim(m, n_envs=E)
+    sim.data.qpos.copy_(torch.as_tensor(q))
+    sim.data.ctrl.copy_(torch.as_tensor(c))
+    sim.forward()
+    sim.sync()
+    qacc = sim.data.qacc.cpu().numpy()
+    it = sim.data.solver_iter.cpu().numpy()
+    for e in range(0, E, 7):
+        ref, s = _oracle_forward(m, q[e], v[e], c[e], ["qacc"])
+        err = np.abs(qacc[e] - ref["qacc"]).max() / max(1.0, np.abs(ref["qacc"]).max())
+        assert err < 1e-8, (e, err)
+        assert abs(int(it[e]) - s.solver_iter) <= 1
+    sim.step(100)
+    sim.sync()
+    assert np.isfinite(sim.data.qpos.cpu().numpy()).all()

@@ -199,3 +199,20 @@ def test_nan_guard_resets(cf_model):
     s.qpos[2] = np.nan
     s.step()
     assert s.warning & 1 and np.isfinite(s.qpos).all()
+
+
+def test_pgs_newton_same_fixed_point(hand_model):
+    """Newton (primal) and PGS (dual, explicit A+R) minimise the same convex problem."""
+    for contacts in (False, True):
+        m = hand_model.copy() if contacts else workload.contact_free(hand_model)
+        mp = m.copy()
+        mp.opt_solver = 0
+        mp.opt_iterations = 1000
+        mp.opt_tolerance = 1e-12
+        q, v = workload.config2_state(m, 3, seed=1235)
+        for e in range(3):
+            a, b = OracleSim(m), OracleSim(mp)
+            for s in (a, b):
+                s.qpos[:] = q[e]
+                s.forward()
+            assert np.abs(a.qacc - b.qacc).max() < 1e-5 * max(1.0, np.abs(a.qacc).max())
