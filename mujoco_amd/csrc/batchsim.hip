@@ -455,6 +455,23 @@ static int model_image(bs_model* m, int device, const DeviceImage** out) {
   PUT_CI(mesh_vertadr, s.mesh_vertadr, s.nmesh);
   PUT_CI(hull_adj_start, s.hull_adj_start, s.nhullvert > 0 ? s.nhullvert + 1 : 0);
   PUT_CI(hull_adj, s.hull_adj, s.nhulladj);
+  // climb warm-start table: exhaustive support vertex for the centre direction of every bin
+  std::vector<int32_t> hstart((size_t)(s.nmesh > 0 ? s.nmesh : 1) * BS_NSTART, 0);
+  for (int me = 0; me < s.nmesh; me++) {
+    const double* V = s.hull_vert + 3 * (size_t)s.mesh_vertadr[me];
+    for (int bin = 0; bin < BS_NSTART; bin++) {
+      double dd[3];
+      bin_dir(bin, dd);
+      int best = 0;
+      double bv = -1e300;
+      for (int v = 0; v < s.mesh_vertnum[me]; v++) {
+        const double val = V[3 * v] * dd[0] + V[3 * v + 1] * dd[1] + V[3 * v + 2] * dd[2];
+        if (val > bv) { bv = val; best = v; }
+      }
+      hstart[(size_t)me * BS_NSTART + bin] = best;
+    }
+  }
+  PUT_CI(hull_start, hstart.data(), hstart.size());
 #undef PUT_CI
 #undef PUT_CD
   TpModel tp = m->tp;

@@ -24,7 +24,33 @@ struct ColModel {
   const double *geom_rbound, *geom_margin, *geom_gap, *geom_friction, *geom_solref, *geom_solimp,
       *geom_solmix, *hull_vert;
   const int *mesh_vertadr, *hull_adj_start, *hull_adj;
+  const int *hull_start;  // [nmesh][BS_NSTART] support vertex for a cube-map of directions (climb warm start)
 };
+
+// cube-map direction bins: 6 faces x BS_SG x BS_SG
+#define BS_SG 4
+#define BS_NSTART (6 * BS_SG * BS_SG)
+__host__ __device__ inline int dir_bin(double x, double y, double z) {
+  const double ax = x < 0 ? -x : x, ay = y < 0 ? -y : y, az = z < 0 ? -z : z;
+  int face;
+  double u, v, w;
+  if (ax >= ay && ax >= az) { face = x < 0 ? 1 : 0; w = ax; u = y; v = z; }
+  else if (ay >= az) { face = y < 0 ? 3 : 2; w = ay; u = x; v = z; }
+  else { face = z < 0 ? 5 : 4; w = az; u = x; v = y; }
+  if (!(w > 0)) return 0;
+  int iu = (int)((u / w * 0.5 + 0.5) * BS_SG), iv = (int)((v / w * 0.5 + 0.5) * BS_SG);
+  iu = iu < 0 ? 0 : (iu >= BS_SG ? BS_SG - 1 : iu);
+  iv = iv < 0 ? 0 : (iv >= BS_SG ? BS_SG - 1 : iv);
+  return (face * BS_SG + iu) * BS_SG + iv;
+}
+// centre direction of a bin (host: table construction)
+inline void bin_dir(int bin, double* d) {
+  const int iv = bin % BS_SG, iu = (bin / BS_SG) % BS_SG, face = bin / (BS_SG * BS_SG);
+  const double u = ((iu + 0.5) / BS_SG - 0.5) * 2, v = ((iv + 0.5) / BS_SG - 0.5) * 2, s = (face & 1) ? -1.0 : 1.0;
+  if (face < 2) { d[0] = s; d[1] = u; d[2] = v; }
+  else if (face < 4) { d[0] = u; d[1] = s; d[2] = v; }
+  else { d[0] = u; d[1] = v; d[2] = s; }
+}
 
 struct ColData {
   // geom frames (the sim's derived buffers)
@@ -59,7 +85,7 @@ __device__ __forceinline__ bool v_eq(const V3& a, const V3& b) {
 
 struct CObj {
   const double* vert;
-  const int *adj_start, *adj;
+  const int *adj_start, *adj, *start;
   int vertadr, cache;
   V3 xpos;
   M3 R;
@@ -74,6 +100,12 @@ __device__ inline V3 hull_support(CObj& o, const V3& dir) {
   int imax = o.cache, prev = -1;
   const double* v0 = o.vert + 3 * imax;
   double vmax = v0[0] * d.x + v0[1] * d.y + v0[2] * d.z;
+  {  // better of (previous support vertex, table vertex for this direction bin) as the start
+    const int t = o.start[dir_bin(d.x, d.y, d.z)];
+    const double* vt = o.vert + 3 * t;
+    const double val = vt[0] * d.x + vt[1] * d.y + vt[2] * d.z;
+    if (val > vmax) { vmax = val; imax = t; }
+  }
   while (imax != prev) {
     prev = imax;
     const int g = o.vertadr + prev;
@@ -306,6 +338,7 @@ __device__ inline void col_narrowphase(const ColModel& cm, const DevData& d, con
     b.vertadr = cm.mesh_vertadr[mesh];
     b.vert = cm.hull_vert + 3 * (size_t)b.vertadr;
     b.adj_start = cm.hull_adj_start; b.adj = cm.hull_adj; b.cache = 0;
+    b.start = cm.hull_start + (size_t)mesh * BS_NSTART;
     b.xpos = {AT(c.geom_xpos, 3 * g2), AT(c.geom_xpos, 3 * g2 + 1), AT(c.geom_xpos, 3 * g2 + 2)};
     for (int k = 0; k < 9; k++) b.R.a[k] = AT(c.geom_xmat, 9 * g2 + k);
   }
@@ -328,6 +361,7 @@ __device__ inline void col_narrowphase(const ColModel& cm, const DevData& d, con
     a.vertadr = cm.mesh_vertadr[mesh];
     a.vert = cm.hull_vert + 3 * (size_t)a.vertadr;
     a.adj_start = cm.hull_adj_start; a.adj = cm.hull_adj; a.cache = 0;
+    a.start = cm.hull_start + (size_t)mesh * BS_NSTART;
     a.xpos = {AT(c.geom_xpos, 3 * g1), AT(c.geom_xpos, 3 * g1 + 1), AT(c.geom_xpos, 3 * g1 + 2)};
     for (int k = 0; k < 9; k++) a.R.a[k] = AT(c.geom_xmat, 9 * g1 + k);
     a.margin = 0.5 * margin; b.margin = 0.5 * margin;
