@@ -508,6 +508,7 @@ struct bs_sim {
   ColData cd;
   ConData kd;
   void* carena = nullptr;
+  size_t hs_bytes = 0;  // dynamic LDS of k_c_dyn (0 = Hessian in the global arena)
   DevData dd;
   int device = 0;
   long n_envs = 0, E = 0;
@@ -618,12 +619,13 @@ __global__ __launch_bounds__(BS_BLOCK) void k_c_narrow(ColModel cm, DevData d, C
   col_narrowphase(cm, d, c, e, blockIdx.y);
 }
 __global__ __launch_bounds__(BS_BLOCK) void k_c_dyn(DevModel m, ColModel cm, DevData d, ColData c, ConData k,
-                                                    int integrate) {
+                                                    int integrate, int lds_hessian) {
+  extern __shared__ double hs_lds[];  // dense Hessian + one Jacobian row per lane, [entry][64]
   const long e = (long)blockIdx.x * BS_BLOCK + threadIdx.x;
   if (e >= d.n_envs) return;
   col_assemble(cm, d, c, e);
   stage_velocity(m, d, e);
-  stage_constraint_c(m, cm, d, c, k, e);
+  stage_constraint_c(m, cm, d, c, k, e, lds_hessian ? hs_lds : nullptr);
   if (integrate) {
     // mj_checkAcc: a bad acceleration resets the environment; the next step recomputes everything
     if (!env_check(m, d, e, d.qacc, m.nv, 2)) stage_euler(m, d, e);
@@ -637,7 +639,8 @@ static void launch_contact_pass(bs_sim* s, int check, int integrate) {
   hipLaunchKernelGGL(k_c_pos, g, dim3(BS_BLOCK), 0, s->stream, s->dm, s->dd, s->cd, check);
   hipLaunchKernelGGL(k_c_broad, dim3((unsigned)s->n_envs), dim3(64), 0, s->stream, s->cm, s->dd, s->cd);
   hipLaunchKernelGGL(k_c_narrow, dim3(g.x, (unsigned)s->cm.maxcand), dim3(BS_BLOCK), 0, s->stream, s->cm, s->dd, s->cd);
-  hipLaunchKernelGGL(k_c_dyn, g, dim3(BS_BLOCK), 0, s->stream, s->dm, s->cm, s->dd, s->cd, s->kd, integrate);
+  hipLaunchKernelGGL(k_c_dyn, g, dim3(BS_BLOCK), s->hs_bytes, s->stream, s->dm, s->cm, s->dd, s->cd, s->kd, integrate,
+                     s->hs_bytes ? 1 : 0);
 }
 static void launch_step(bs_sim* s, int n_steps) {
   if (s->contacts) {
@@ -782,6 +785,14 @@ extern "C" int bs_sim_create(const bs_model* const* models, int n_models, const 
     k.ncrow = takei(1); k.con_efc = takei(mk);
     c.stat = (unsigned long long*)(((uintptr_t)ip + 7) & ~(uintptr_t)7);
     s->fields[BS_F_NCON] = {c.ncon, 1, true};
+    // dense Hessian in LDS when (nv(nv+1)/2 + nv) x 64 lanes x 8 B fits one CU's 160 KB
+    const size_t want = (nh + (size_t)nv) * BS_BLOCK * sizeof(double);
+    if (want <= 160 * 1024 && getenv("BS_LDS_HESSIAN")) {  // opt-in: lowers occupancy to one wave per CU
+      if (hipFuncSetAttribute((const void*)k_c_dyn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want) == hipSuccess)
+        s->hs_bytes = want;
+      else
+        (void)hipGetLastError();
+    }
   } else {
     s->fields[BS_F_NCON] = {d.nefc, 0, true};  // zero rows: no contacts in this sim
   }
@@ -960,7 +971,8 @@ extern "C" int bs_stage_times(bs_sim* s, double* ms, int n) {
     hipLaunchKernelGGL(k_c_broad, dim3((unsigned)s->n_envs), dim3(64), 0, s->stream, s->cm, s->dd, s->cd);
     hipLaunchKernelGGL(k_c_narrow, dim3(g.x, (unsigned)s->cm.maxcand), dim3(BS_BLOCK), 0, s->stream, s->cm, s->dd, s->cd);
     HIPCHK(hipEventRecord(s->ev[2], s->stream));
-    hipLaunchKernelGGL(k_c_dyn, g, dim3(BS_BLOCK), 0, s->stream, s->dm, s->cm, s->dd, s->cd, s->kd, 1);
+    hipLaunchKernelGGL(k_c_dyn, g, dim3(BS_BLOCK), s->hs_bytes, s->stream, s->dm, s->cm, s->dd, s->cd, s->kd, 1,
+                       s->hs_bytes ? 1 : 0);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(s->ev[3], s->stream));
     HIPCHK(hipEventSynchronize(s->ev[3]));

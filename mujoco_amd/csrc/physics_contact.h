@@ -136,8 +136,12 @@ __device__ inline double cost_at_c(const DevModel& m, const DevData& d, const Co
 }
 
 // dense H = M + J^T D_active J, Cholesky, search = -H^-1 grad
+// `hs`: optional LDS block of (nv(nv+1)/2 + nv) x 64 doubles ([entry][lane]); when given, the
+// Hessian and the staged Jacobian row live there instead of the global arena (the dense
+// factorisation is otherwise bound by L2/HBM traffic).
+#define HDX(q) (*(hs ? hs + (size_t)(q) * 64 + threadIdx.x : &AT(k.Hd, q)))
 __device__ inline double update_gradient_dense(const DevModel& m, const DevData& d, const ConData& k, long e,
-                                               int ncrow) {
+                                               int ncrow, double* hs) {
   const long E = d.E;
   const int nv = m.nv;
   double gg = 0;
@@ -147,65 +151,76 @@ __device__ inline double update_gradient_dense(const DevModel& m, const DevData&
     AT(d.Mgrad, i) = g;
     gg += g * g;
   }
-  for (int q = 0; q < nv * (nv + 1) / 2; q++) AT(k.Hd, q) = 0;
+  for (int q = 0; q < nv * (nv + 1) / 2; q++) HDX(q) = 0;
   for (int i = 0; i < nv; i++) {
     int adr = m.dof_Madr[i];
-    for (int j = i; j >= 0; j = m.dof_parentid[j], adr++) AT(k.Hd, tri_idx(i, j)) = AT(d.qM, adr);
+    for (int j = i; j >= 0; j = m.dof_parentid[j], adr++) HDX(tri_idx(i, j)) = AT(d.qM, adr);
   }
   for (int r = 0; r < m.neq; r++) {
     const double D = AT(d.efc_D, r);
     const int a = m.eq_dof1[r], b = m.eq_dof2[r];
-    AT(k.Hd, tri_idx(a, a)) += D;
+    HDX(tri_idx(a, a)) += D;
     if (b >= 0) {
       const double c = AT(d.eq_coef, r);
-      AT(k.Hd, tri_idx(b, b)) += D * c * c;
-      AT(k.Hd, a > b ? tri_idx(a, b) : tri_idx(b, a)) -= D * c;
+      HDX(tri_idx(b, b)) += D * c * c;
+      HDX(a > b ? tri_idx(a, b) : tri_idx(b, a)) -= D * c;
     }
   }
   for (int q = 0; q < m.nfric; q++) {
     const int r = m.neq + q, i = m.fric_dof[q];
     const double x = AT(d.jar, r), rf = AT(d.fric_rf, q);
-    if (x > -rf && x < rf) AT(k.Hd, tri_idx(i, i)) += AT(d.efc_D, r);
+    if (x > -rf && x < rf) HDX(tri_idx(i, i)) += AT(d.efc_D, r);
   }
   for (int q = 0; q < m.nlim; q++) {
     const int r = m.neq + m.nfric + 2 * q, i = m.jnt_dofadr[m.lim_jnt[q]];
     double add = 0;
     if (AT(d.jar, r) < 0) add += AT(d.efc_D, r);
     if (AT(d.jar, r + 1) < 0) add += AT(d.efc_D, r + 1);
-    AT(k.Hd, tri_idx(i, i)) += add;
+    HDX(tri_idx(i, i)) += add;
   }
   for (int r = 0; r < ncrow; r++) {
     if (!(AT(k.cjar, r) < 0)) continue;
     const double D = AT(k.cD, r);
+    if (hs) {
+      double* row = hs + (size_t)(nv * (nv + 1) / 2) * 64 + threadIdx.x;
+      for (int a = 0; a < nv; a++) row[(size_t)a * 64] = AT(k.cJ, (size_t)r * nv + a);
+      for (int a = 0; a < nv; a++) {
+        const double Ja = row[(size_t)a * 64];
+        if (Ja == 0) continue;
+        const double t = D * Ja;
+        for (int b = 0; b <= a; b++) HDX(tri_idx(a, b)) += t * row[(size_t)b * 64];
+      }
+      continue;
+    }
     for (int a = 0; a < nv; a++) {
       const double Ja = AT(k.cJ, (size_t)r * nv + a);
       if (Ja == 0) continue;
       const double t = D * Ja;
-      for (int b = 0; b <= a; b++) AT(k.Hd, tri_idx(a, b)) += t * AT(k.cJ, (size_t)r * nv + b);
+      for (int b = 0; b <= a; b++) HDX(tri_idx(a, b)) += t * AT(k.cJ, (size_t)r * nv + b);
     }
   }
   // Cholesky H = L L^T in place (MuJoCo's MINVAL floor on the pivots)
   for (int j = 0; j < nv; j++) {
-    double s = AT(k.Hd, tri_idx(j, j));
-    for (int q = 0; q < j; q++) { const double l = AT(k.Hd, tri_idx(j, q)); s -= l * l; }
+    double s = HDX(tri_idx(j, j));
+    for (int q = 0; q < j; q++) { const double l = HDX(tri_idx(j, q)); s -= l * l; }
     if (s < BS_MINVAL) s = BS_MINVAL;
     const double l = sqrt(s);
-    AT(k.Hd, tri_idx(j, j)) = l;
+    HDX(tri_idx(j, j)) = l;
     for (int i = j + 1; i < nv; i++) {
-      double t = AT(k.Hd, tri_idx(i, j));
-      for (int q = 0; q < j; q++) t -= AT(k.Hd, tri_idx(i, q)) * AT(k.Hd, tri_idx(j, q));
-      AT(k.Hd, tri_idx(i, j)) = t / l;
+      double t = HDX(tri_idx(i, j));
+      for (int q = 0; q < j; q++) t -= HDX(tri_idx(i, q)) * HDX(tri_idx(j, q));
+      HDX(tri_idx(i, j)) = t / l;
     }
   }
   for (int i = 0; i < nv; i++) {
     double s = AT(d.Mgrad, i);
-    for (int q = 0; q < i; q++) s -= AT(k.Hd, tri_idx(i, q)) * AT(d.Mgrad, q);
-    AT(d.Mgrad, i) = s / AT(k.Hd, tri_idx(i, i));
+    for (int q = 0; q < i; q++) s -= HDX(tri_idx(i, q)) * AT(d.Mgrad, q);
+    AT(d.Mgrad, i) = s / HDX(tri_idx(i, i));
   }
   for (int i = nv - 1; i >= 0; i--) {
     double s = AT(d.Mgrad, i);
-    for (int q = i + 1; q < nv; q++) s -= AT(k.Hd, tri_idx(q, i)) * AT(d.Mgrad, q);
-    AT(d.Mgrad, i) = s / AT(k.Hd, tri_idx(i, i));
+    for (int q = i + 1; q < nv; q++) s -= HDX(tri_idx(q, i)) * AT(d.Mgrad, q);
+    AT(d.Mgrad, i) = s / HDX(tri_idx(i, i));
   }
   for (int i = 0; i < nv; i++) AT(d.search, i) = -AT(d.Mgrad, i);
   return gg;
@@ -290,7 +305,7 @@ __device__ inline void stage_pgs(const DevModel& m, const DevData& d, const ConD
 
 // A7 + A11 with contacts
 __device__ inline void stage_constraint_c(const DevModel& m, const ColModel& cm, const DevData& d, const ColData& c,
-                                          const ConData& k, long e) {
+                                          const ConData& k, long e, double* hs) {
   const long E = d.E;
   int nact = 0, ncrow = 0;
   if (!(m.disableflags & BS_DSBL_CONSTRAINT)) {
@@ -332,7 +347,7 @@ __device__ inline void stage_constraint_c(const DevModel& m, const ColModel& cm,
   };
   double gauss;
   double cost = update(gauss);
-  update_gradient_dense(m, d, k, e, ncrow);
+  update_gradient_dense(m, d, k, e, ncrow, hs);
   int iter = 0;
   while (iter < m.iterations) {
     const double alpha = line_search_c(m, d, k, e, ncrow, gauss, scale);
@@ -345,7 +360,7 @@ __device__ inline void stage_constraint_c(const DevModel& m, const ColModel& cm,
     for (int r = 0; r < ncrow; r++) AT(k.cjar, r) += alpha * AT(k.cjv, r);
     const double oldcost = cost;
     cost = update(gauss);
-    const double gg = update_gradient_dense(m, d, k, e, ncrow);
+    const double gg = update_gradient_dense(m, d, k, e, ncrow, hs);
     iter++;
     const double improvement = scale * (oldcost - cost), gradient = scale * sqrt(gg);
     if (improvement < m.tolerance || gradient < m.tolerance) break;
