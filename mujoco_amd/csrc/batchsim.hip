@@ -157,6 +157,13 @@ static void build_tp(bs_model* m) {
   const int neq = (int)m->eq_dof1.size(), nfric = (int)m->fric_dof.size();
   for (int k = 0; k < nfric; k++) at(TPI_FRIC_ROW, s.dof_bodyid[m->fric_dof[k]]) = neq + k;
   for (size_t k = 0; k < m->lim_jnt.size(); k++) at(TPI_LIM_ROW, s.jnt_bodyid[m->lim_jnt[k]]) = neq + nfric + 2 * (int)k;
+  for (int l = 0; l < TP_LPE; l++) at(TPI_ANCMASK, l) = 0;
+  for (int b = 1; b < nb; b++) {
+    uint32_t mask = 0;
+    for (int a = b; a > 0; a = s.body_parentid[a])
+      if (jnt_of[a] >= 0) mask |= 1u << a;
+    at(TPI_ANCMASK, b) = (int32_t)mask;
+  }
   m->tp.maxdepth = maxdepth; m->tp.maxdd = maxdd; m->tp.nroots = nroots;
   m->tp_ok = 1;
 }
@@ -503,6 +510,7 @@ struct bs_sim {
   DevModel dm;
   TpModel tp;
   bool use_tp = false;
+  bool use_tpc = false;  // contacts: tree-parallel dynamics kernel instead of the serial k_c_dyn (steps only)
   bool contacts = false;
   ColModel cm;
   ColData cd;
@@ -533,7 +541,20 @@ __global__ __launch_bounds__(BS_BLOCK) void k_step(DevModel m, DevData d, int ns
 // tree-parallel kernel: 2 environments per 64-lane block (physics_tp.h)
 __global__ __launch_bounds__(64, 2) void k_tp(DevModel m, TpModel t, DevData d, int nsteps, int mode, int dump) {
   __shared__ int tbl[TPI_TOTAL * 64];
-  tp_run(m, t, d, nsteps, mode, dump, tbl);
+  const TpShared sh = {tbl, nullptr, nullptr, nullptr};
+  ColModel cm;
+  ColData cd;
+  tp_run<false>(m, t, d, nsteps, mode, dump, sh, cm, cd);
+}
+// tree-parallel step with contacts: candidates from k_c_broad / k_c_narrow, one step per launch
+__global__ __launch_bounds__(64, 1) void k_tpc(DevModel m, TpModel t, DevData d, ColModel cm, ColData cd, int mode,
+                                               int dump) {
+  __shared__ int tbl[TPI_TOTAL * 64];
+  __shared__ double hH[2 * TPC_HTRI];
+  __shared__ double cg[2 * TP_LPE * TPC_SLOT];
+  __shared__ double U[2 * TP_LPE * 3];
+  const TpShared sh = {tbl, hH, cg, U};
+  tp_run<true>(m, t, d, 1, mode, dump, sh, cm, cd);
 }
 __global__ __launch_bounds__(BS_BLOCK) void k_forward(DevModel m, DevData d) {
   const long e = (long)blockIdx.x * BS_BLOCK + threadIdx.x;
@@ -639,6 +660,10 @@ static void launch_contact_pass(bs_sim* s, int check, int integrate) {
   hipLaunchKernelGGL(k_c_pos, g, dim3(BS_BLOCK), 0, s->stream, s->dm, s->dd, s->cd, check);
   hipLaunchKernelGGL(k_c_broad, dim3((unsigned)s->n_envs), dim3(64), 0, s->stream, s->cm, s->dd, s->cd);
   hipLaunchKernelGGL(k_c_narrow, dim3(g.x, (unsigned)s->cm.maxcand), dim3(BS_BLOCK), 0, s->stream, s->cm, s->dd, s->cd);
+  if (s->use_tpc && integrate) {
+    hipLaunchKernelGGL(k_tpc, grid_tp(s), dim3(64), 0, s->stream, s->dm, s->tp, s->dd, s->cm, s->cd, 0, 1);
+    return;
+  }
   hipLaunchKernelGGL(k_c_dyn, g, dim3(BS_BLOCK), s->hs_bytes, s->stream, s->dm, s->cm, s->dd, s->cd, s->kd, integrate,
                      s->hs_bytes ? 1 : 0);
 }
@@ -687,6 +712,8 @@ extern "C" int bs_sim_create(const bs_model* const* models, int n_models, const 
   s->cm.maxcon = (opt && opt->max_contacts_per_env > 0) ? opt->max_contacts_per_env : 32;
   s->cm.maxcand = model->d.npair < 256 ? model->d.npair : 256;
   s->use_tp = !contacts && model->d.solver == 2 && model->tp_ok && !(kv && strcmp(kv, "serial") == 0);
+  s->use_tpc = contacts && model->d.solver == 2 && model->tp_ok && s->cm.maxcon <= TP_LPE &&
+               !(kv && strcmp(kv, "serial") == 0);
   if (kv && strcmp(kv, "tp") == 0 && !model->tp_ok) {
     delete s;
     return fail(BS_ERR_UNSUPPORTED, "BS_KERNEL=tp but the model is not eligible: %s", model->tp_why.c_str());

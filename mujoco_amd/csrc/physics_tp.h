@@ -15,7 +15,7 @@
 //
 // Stage semantics and reference citations are those of physics_dev.h.
 #pragma once
-#include "physics_dev.h"
+#include "physics_collide.h"
 
 #define TP_LPE 32   // lanes per environment
 #define TP_MAXD 6   // max entries in a dof's mass-matrix row (itself + 5 ancestor dofs)
@@ -33,7 +33,9 @@ enum {
   TPI_BCHILD = TPI_ANC + TP_MAXD,            // + c
   TPI_DCHILD = TPI_BCHILD + TP_MAXC,         // + c
   TPI_COUNT = TPI_DCHILD + TP_MAXC,
-  TPI_FRIC_ROW = TPI_COUNT, TPI_LIM_ROW, TPI_TOTAL
+  TPI_FRIC_ROW = TPI_COUNT, TPI_LIM_ROW,
+  TPI_ANCMASK,  // bit k set: body lane k carries a dof on the path from this body to the root (itself included)
+  TPI_TOTAL
 };
 
 struct TpModel {
@@ -87,6 +89,21 @@ __device__ __forceinline__ constexpr int pair_idx(int a, int b) {  // 1 <= a <= 
 }
 
 typedef const int __attribute__((address_space(3))) * tp_lds_ptr;  // lane table in LDS
+typedef double __attribute__((address_space(3))) * tp_lds_d;
+typedef int __attribute__((address_space(3))) * tp_lds_i;
+
+// ---- contacts in the tree-parallel layout (k_tpc): contact c of an environment is owned by lane
+// c (so at most 32 contacts); its geometry lives in an LDS slot, its rows in the lane's registers.
+#define TPC_SLOT 21                              // doubles per contact slot (odd stride)
+#define TPC_HTRI (TP_LPE * (TP_LPE + 1) / 2)     // packed lower-triangular Hessian, one per env
+enum { CG_POS = 0, CG_FRAME = 3, CG_DIST = 12, CG_PAIR = 13, CG_C = 14, CG_MASK = 19 };
+struct TpShared { int* tbl; double* H; double* cg; double* U; };
+// the two environments of a wavefront diverge, so LDS hand-offs between lanes of one environment
+// are ordered with a fence + scheduling barrier instead of s_barrier (LDS is in-order per wave)
+__device__ __forceinline__ void tp_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+}
 struct TpRow { double r[TP_MAXD]; };
 struct TpFac { TpRow R; double dinv; };
 
@@ -247,12 +264,14 @@ struct TpRows {
   double De, aref_e, ce;         // owned equality: J = e_own - ce * e_other
   double De_o, ce_o;             // equality in which this dof is the 'other' one (from its owner)
   bool own;                      // owns an equality row
+  double cD;                     // contact owned by this lane: D of its (up to 4) pyramid rows, 0 = none
 };
 
 struct TpSol {
   double qacc, Ma, grad, search, Mv;
   double jf, jl0, jl1, je;      // residuals J*qacc - aref
   double vf, vl0, vl1, ve;      // J*search
+  double cj[4], cv[4];          // contact rows (k_tpc only): residuals and J*search
 };
 
 // impedance with the common power == 2 case evaluated without pow()
@@ -288,10 +307,31 @@ __device__ __forceinline__ double tp_rows_cost(const TpRows& r, double jf, doubl
   return cost;
 }
 
+// cost (and forces) of the lane's contact rows: f = -D * min(jar, 0)
+template <bool FORCE>
+__device__ __forceinline__ double tp_con_cost(double D, const double* cj, double* cf) {
+  double cost = 0;
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const double x = cj[q];
+    if (FORCE) cf[q] = x < 0 ? -D * x : 0.0;
+    if (x < 0) cost += 0.5 * D * x * x;
+  }
+  return cost;
+}
+
 struct TpLs { double alpha, cost, d0, d1; };
 
+template <bool CON>
 __device__ TP_HELPER_ATTR TpLs tp_ls_eval(TpRows r, TpSol s, double alpha, double g0, double g1, double g2) {
   double q0 = 0, q1 = 0, q2 = 0;
+  if constexpr (CON) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const double x = s.cj[q] + alpha * s.cv[q];
+      if (x < 0) { q0 += 0.5 * r.cD * x * x; q1 += r.cD * x * s.cv[q]; q2 += 0.5 * r.cD * s.cv[q] * s.cv[q]; }
+    }
+  }
   if (r.own) {
     const double x = s.je + alpha * s.ve;
     q0 += 0.5 * r.De * x * x; q1 += r.De * x * s.ve; q2 += 0.5 * r.De * s.ve * s.ve;
@@ -321,6 +361,7 @@ __device__ TP_HELPER_ATTR TpLs tp_ls_eval(TpRows r, TpSol s, double alpha, doubl
 }
 
 // exact line search (same shape as physics_dev.h::line_search); all values are env-uniform
+template <bool CON>
 __device__ __forceinline__ double tp_line_search(const DevModel& m, const TpRows& r, const TpSol& s,
                                                  double gauss, double scale, double qfrc_smooth) {
   const double snorm = sqrt(env_sum(s.search * s.search));
@@ -330,8 +371,8 @@ __device__ __forceinline__ double tp_line_search(const DevModel& m, const TpRows
   const double g2 = 0.5 * env_sum(s.search * s.Mv);
   int it = 0;
   const int maxit = m.ls_iterations;
-  const TpLs p0 = tp_ls_eval(r, s, 0.0, gauss, g1, g2);
-  TpLs p1 = tp_ls_eval(r, s, p0.alpha - p0.d0 / p0.d1, gauss, g1, g2);
+  const TpLs p0 = tp_ls_eval<CON>(r, s, 0.0, gauss, g1, g2);
+  TpLs p1 = tp_ls_eval<CON>(r, s, p0.alpha - p0.d0 / p0.d1, gauss, g1, g2);
   if (p0.cost < p1.cost) p1 = p0;
   if (fabs(p1.d0) < gtol) return p1.alpha;
   const double dir = p1.d0 < 0 ? 1.0 : -1.0;
@@ -339,15 +380,15 @@ __device__ __forceinline__ double tp_line_search(const DevModel& m, const TpRows
   TpLs p2 = p1;
   while (p1.d0 * dir <= -gtol && it < maxit) {
     p2 = p1; p2update = true;
-    p1 = tp_ls_eval(r, s, p1.alpha - p1.d0 / p1.d1, gauss, g1, g2);
+    p1 = tp_ls_eval<CON>(r, s, p1.alpha - p1.d0 / p1.d1, gauss, g1, g2);
     it++;
     if (fabs(p1.d0) < gtol) return p1.alpha;
   }
   if (it >= maxit || !p2update) return p1.alpha;
   TpLs p2next = p1;
-  TpLs p1next = tp_ls_eval(r, s, p1.alpha - p1.d0 / p1.d1, gauss, g1, g2);
+  TpLs p1next = tp_ls_eval<CON>(r, s, p1.alpha - p1.d0 / p1.d1, gauss, g1, g2);
   while (it < maxit) {
-    const TpLs pmid = tp_ls_eval(r, s, 0.5 * (p1.alpha + p2.alpha), gauss, g1, g2);
+    const TpLs pmid = tp_ls_eval<CON>(r, s, 0.5 * (p1.alpha + p2.alpha), gauss, g1, g2);
     it++;
     bool b1 = false, b2 = false;
 #pragma unroll
@@ -361,8 +402,8 @@ __device__ __forceinline__ double tp_line_search(const DevModel& m, const TpRows
       }
     }
     if (!b1 && !b2) break;
-    if (b1) p1next = tp_ls_eval(r, s, p1.alpha - p1.d0 / p1.d1, gauss, g1, g2);
-    if (b2) p2next = tp_ls_eval(r, s, p2.alpha - p2.d0 / p2.d1, gauss, g1, g2);
+    if (b1) p1next = tp_ls_eval<CON>(r, s, p1.alpha - p1.d0 / p1.d1, gauss, g1, g2);
+    if (b2) p2next = tp_ls_eval<CON>(r, s, p2.alpha - p2.d0 / p2.d1, gauss, g1, g2);
   }
   const TpLs best = p1.cost <= p2.cost ? p1 : p2;
   return best.cost < p0.cost ? best.alpha : 0.0;
@@ -371,8 +412,12 @@ __device__ __forceinline__ double tp_line_search(const DevModel& m, const TpRows
 // ------------------------------------------------------------------ kernel body
 // mode 0: nsteps x mj_step; mode 1: one mj_forward.  dump 0: state only, 1: + poses and
 // generalized forces of the last forward pass, 2: every intermediate the parity tests read.
+// CON: one step per launch with the contact candidates of k_c_broad / k_c_narrow (physics_collide.h):
+// contact assembly, pyramid rows owned by lanes, dense Hessian per environment in LDS.
+template <bool CON>
 __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, const DevData& d, int nsteps,
-                                       int mode, int dump, int* tbl) {
+                                       int mode, int dump, TpShared sh, const ColModel& cm, const ColData& cd) {
+  int* tbl = sh.tbl;
   const int tid = threadIdx.x;
   const int l = tid & (TP_LPE - 1), base = tid & ~(TP_LPE - 1);
   // lane table -> LDS; lane references become ds_bpermute byte addresses
@@ -642,12 +687,153 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
       const double qfrc_smooth = has_dof ? qfrc_passive - qfrc_bias + qfrc_applied + qfrc_actuator : 0.0;
       const double qacc_smooth = tp_solve(c, LM.R, LM.dinv, qfrc_smooth);
 
+      // ---- contacts (k_tpc): ordered hit compaction (same arithmetic as col_assemble) and the
+      // pyramid rows of the contact this lane owns (same arithmetic as make_contact_rows)
+      const bool con_on = !(m.disableflags & BS_DSBL_CONSTRAINT);
+      double caref[4] = {0, 0, 0, 0}, cmu = 0, cDrow = 0;
+      int cnr = 0, b1_sa = self_sa, b2_sa = self_sa;
+      V3 off1 = {0, 0, 0}, off2 = {0, 0, 0};
+      tp_lds_d slot0 = nullptr, myslot = nullptr, Hs = nullptr, Us = nullptr;
+      // u3 = (normal, tangent1, tangent2) components of J_contact * x for the lane's contact:
+      // x is pushed down the body tree like a velocity (sum of cdof * x over the chain), then the
+      // owner lane reads the spatial vectors of its two bodies and projects their difference
+      auto con_jx = [&](double x, double* u3) {
+        if constexpr (CON) {
+          double cv[6] = {0, 0, 0, 0, 0, 0};
+          for (int lvl = 1; lvl <= t.maxdepth; lvl++) {
+            double pv[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) pv[k] = bperm(cv[k], par_sa);
+            if (isb && depth == lvl)
+#pragma unroll
+              for (int k = 0; k < 6; k++) cv[k] = pv[k] + cdof[k] * x;
+          }
+          double v1[6], v2[6];
+#pragma unroll
+          for (int k = 0; k < 6; k++) { v1[k] = bperm(cv[k], b1_sa); v2[k] = bperm(cv[k], b2_sa); }
+          u3[0] = u3[1] = u3[2] = 0;
+          if (cnr > 0) {
+            const V3 w1 = cross(V3{v1[0], v1[1], v1[2]}, off1), w2 = cross(V3{v2[0], v2[1], v2[2]}, off2);
+            const V3 rv = {(v2[3] + w2.x) - (v1[3] + w1.x), (v2[4] + w2.y) - (v1[4] + w1.y),
+                           (v2[5] + w2.z) - (v1[5] + w1.z)};
+            const tp_lds_d f = myslot + CG_FRAME;
+            u3[0] = f[0] * rv.x + f[1] * rv.y + f[2] * rv.z;
+            u3[1] = f[3] * rv.x + f[4] * rv.y + f[5] * rv.z;
+            u3[2] = f[6] * rv.x + f[7] * rv.y + f[8] * rv.z;
+          }
+        }
+      };
+      auto con_rows = [&](const double* u3, double sub, double* out) {
+        out[0] = cnr > 0 ? (u3[0] + cmu * u3[1]) - sub * caref[0] : 0.0;
+        out[1] = cnr > 1 ? (u3[0] - cmu * u3[1]) - sub * caref[1] : 0.0;
+        out[2] = cnr > 1 ? (u3[0] + cmu * u3[2]) - sub * caref[2] : 0.0;
+        out[3] = cnr > 1 ? (u3[0] - cmu * u3[2]) - sub * caref[3] : 0.0;
+      };
+      if constexpr (CON) {
+        const int half = tid / TP_LPE;
+        slot0 = (tp_lds_d)sh.cg + half * (TP_LPE * TPC_SLOT);
+        myslot = slot0 + l * TPC_SLOT;
+        Hs = (tp_lds_d)sh.H + half * TPC_HTRI;
+        Us = (tp_lds_d)sh.U + half * (TP_LPE * 3);
+        const int ncand = AT(cd.ncand, 0);
+        int count = 0;
+        for (int s0 = 0; s0 < cm.maxcand; s0 += TP_LPE) {
+          if (!__ballot(s0 < ncand)) break;
+          const int sidx = s0 + l;
+          const bool hit = sidx < ncand && AT(cd.cand_hit, sidx) != 0;
+          const unsigned bits = (unsigned)(__ballot(hit) >> base);
+          const int n = count + __popc(bits & ((1u << l) - 1u));
+          if (hit && n < cm.maxcon) {
+            const int pr = AT(cd.cand_pair, sidx);
+            const double dist = AT(cd.cand_dist, sidx);
+            const V3 p = {AT(cd.cand_pos, 3 * sidx), AT(cd.cand_pos, 3 * sidx + 1), AT(cd.cand_pos, 3 * sidx + 2)};
+            const V3 x = normalized(V3{AT(cd.cand_nrm, 3 * sidx), AT(cd.cand_nrm, 3 * sidx + 1), AT(cd.cand_nrm, 3 * sidx + 2)});
+            V3 y = {0, 0, 0};
+            if (x.y < 0.5 && x.y > -0.5) y.y = 1;
+            else y.z = 1;
+            const double tt = dot(x, y);
+            y = normalized(V3{y.x - tt * x.x, y.y - tt * x.y, y.z - tt * x.z});
+            const V3 z = cross(x, y);
+            const double fr[9] = {x.x, x.y, x.z, y.x, y.y, y.z, z.x, z.y, z.z};
+            const tp_lds_d sl = slot0 + n * TPC_SLOT;
+            sl[CG_POS] = p.x; sl[CG_POS + 1] = p.y; sl[CG_POS + 2] = p.z;
+#pragma unroll
+            for (int k = 0; k < 9; k++) sl[CG_FRAME + k] = fr[k];
+            sl[CG_DIST] = dist;
+            ((tp_lds_i)(sl + CG_PAIR))[0] = pr;
+            if (env_ok) {
+              AT(cd.con_pair, n) = pr; AT(cd.con_dist, n) = dist;
+              AT(cd.con_pos, 3 * n) = p.x; AT(cd.con_pos, 3 * n + 1) = p.y; AT(cd.con_pos, 3 * n + 2) = p.z;
+#pragma unroll
+              for (int k = 0; k < 9; k++) AT(cd.con_frame, 9 * n + k) = fr[k];
+            }
+          }
+          count += __popc(bits);
+        }
+        if (count > cm.maxcon) { count = cm.maxcon; warning |= 8; }
+        if (env_ok && l == 0) {
+          AT(cd.ncon, 0) = count;
+          if (cd.stat && count) atomicAdd(cd.stat + 2, (unsigned long long)count);
+        }
+        tp_wave_sync();
+        double cB = 0, ckimp = 0;
+        V3 cpos = {0, 0, 0};
+        if (l < count && con_on) {
+          const int pr = ((tp_lds_i)(myslot + CG_PAIR))[0];
+          const int g1 = cm.pair_geom1[pr], g2 = cm.pair_geom2[pr];
+          const int b1 = cm.geom_bodyid[g1], b2 = cm.geom_bodyid[g2];
+          b1_sa = (base + b1) * 4; b2_sa = (base + b2) * 4;
+          ((tp_lds_i)(myslot + CG_MASK))[0] = tbl[TPI_ANCMASK * 64 + base + b1];
+          ((tp_lds_i)(myslot + CG_MASK))[1] = tbl[TPI_ANCMASK * 64 + base + b2];
+          cpos = {myslot[CG_POS], myslot[CG_POS + 1], myslot[CG_POS + 2]};
+          const double margin = fmax(cm.geom_margin[g1], cm.geom_margin[g2]) - fmax(cm.geom_gap[g1], cm.geom_gap[g2]);
+          const double dist = myslot[CG_DIST];
+          if (dist < margin) {
+            const int dim = cm.geom_condim[g1] > cm.geom_condim[g2] ? cm.geom_condim[g1] : cm.geom_condim[g2];
+            const double mu = fmax(cm.geom_friction[3 * g1], cm.geom_friction[3 * g2]);
+            const double s1 = cm.geom_solmix[g1], s2 = cm.geom_solmix[g2];
+            double mix;
+            if (s1 >= BS_MINVAL && s2 >= BS_MINVAL) mix = s1 / (s1 + s2);
+            else if (s1 < BS_MINVAL && s2 < BS_MINVAL) mix = 0.5;
+            else mix = s1 < BS_MINVAL ? 0.0 : 1.0;
+            double solref[2], solimp[5];
+#pragma unroll
+            for (int q = 0; q < 2; q++) solref[q] = mix * cm.geom_solref[2 * g1 + q] + (1 - mix) * cm.geom_solref[2 * g2 + q];
+#pragma unroll
+            for (int q = 0; q < 5; q++) solimp[q] = mix * cm.geom_solimp[5 * g1 + q] + (1 - mix) * cm.geom_solimp[5 * g2 + q];
+            double K, B;
+            const double imp = tp_impedance(solimp, dist, margin);
+            kb_from_solref(m, solref, solimp, K, B);
+            const double tran = m.body_invweight0[2 * b1] + m.body_invweight0[2 * b2];
+            const double diag = dim == 1 ? tran : tran + mu * mu * tran;
+            double R = fmax(BS_MINVAL, (1 - imp) * diag / imp);
+            if (dim > 1) {
+              const double mue = mu / sqrt(fmax(BS_MINVAL, m.impratio));
+              R = fmax(BS_MINVAL, 2 * mue * mue * R);
+            }
+            cnr = dim == 1 ? 1 : 4; cmu = dim == 1 ? 0.0 : mu; cDrow = 1.0 / R;
+            cB = B; ckimp = K * imp * (dist - margin);
+          }
+        }
+        {  // converged code: every lane takes part in the permutes
+          const V3 c1 = {bperm(com.x, b1_sa), bperm(com.y, b1_sa), bperm(com.z, b1_sa)};
+          const V3 c2 = {bperm(com.x, b2_sa), bperm(com.y, b2_sa), bperm(com.z, b2_sa)};
+          off1 = {cpos.x - c1.x, cpos.y - c1.y, cpos.z - c1.z};
+          off2 = {cpos.x - c2.x, cpos.y - c2.y, cpos.z - c2.z};
+        }
+        double u3[3], vel[4];
+        con_jx(qvel, u3);
+        con_rows(u3, 0.0, vel);
+#pragma unroll
+        for (int q = 0; q < 4; q++) caref[q] = q < cnr ? -cB * vel[q] - ckimp : 0.0;
+        tp_wave_sync();
+      }
+
       // ---- A7 constraint rows
       TpRows r;
       r.Df = r.rf = r.aref_f = r.fl = 0; r.Dl0 = r.Dl1 = r.aref_l0 = r.aref_l1 = 0;
-      r.De = r.aref_e = r.ce = 0; r.De_o = r.ce_o = 0; r.own = false;
+      r.De = r.aref_e = r.ce = 0; r.De_o = r.ce_o = 0; r.own = false; r.cD = cDrow;
       int nact = 0;
-      const bool con_on = !(m.disableflags & BS_DSBL_CONSTRAINT);
       if (con_on && has_dof) {
         const double iw = m.dof_invweight0[j];
         if (!(m.disableflags & BS_DSBL_FRICTIONLOSS) && m.dof_frictionloss[j] > 0) {
@@ -697,18 +883,167 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
         const double De_s = bperm(r.De, eq_src_sa), ce_s = bperm(r.ce, eq_src_sa);
         if (is_src) { r.De_o = De_s; r.ce_o = ce_s; }
       }
-      nefc = env_sum_i(nact);
+      nefc = env_sum_i(nact + cnr);
 
       // ---- A11 Newton on the dual-free primal (mj_solNewton shape)
       double qfrc_constraint = 0, frc[4] = {0, 0, 0, 0};
+      // J_contact^T f: contacts with a force, in contact order; the owner lane broadcasts the world
+      // force, every dof lane on one of the two body chains projects it on its own motion axis
+      auto con_jtf = [&](const double* cf) -> double {
+        double qc = 0;
+        if constexpr (CON) {
+          V3 Fw = {0, 0, 0};
+          bool hasf = false;
+          if (cnr > 0) {
+            const double fn = (cf[0] + cf[1]) + (cf[2] + cf[3]);
+            const double f1 = cmu * (cf[0] - cf[1]), f2 = cmu * (cf[2] - cf[3]);
+            const tp_lds_d f = myslot + CG_FRAME;
+            Fw = {fn * f[0] + f1 * f[3] + f2 * f[6], fn * f[1] + f1 * f[4] + f2 * f[7], fn * f[2] + f1 * f[5] + f2 * f[8]};
+            hasf = fn != 0;
+          }
+          const unsigned long long fb = __ballot(hasf);
+          const unsigned mine = (unsigned)(fb >> base);
+          unsigned merged = (unsigned)(fb | (fb >> 32));
+          while (merged) {
+            const int ci = __builtin_ctz(merged);
+            merged &= merged - 1;
+            const int sa = (base + ci) * 4;
+            const V3 F = {bperm(Fw.x, sa), bperm(Fw.y, sa), bperm(Fw.z, sa)};
+            if ((mine >> ci) & 1) {
+              const tp_lds_d sl = slot0 + ci * TPC_SLOT;
+              const int m1 = ((tp_lds_i)(sl + CG_MASK))[0], m2 = ((tp_lds_i)(sl + CG_MASK))[1];
+              const int sgn = ((m2 >> l) & 1) - ((m1 >> l) & 1);
+              if (sgn != 0) {
+                const V3 off = {sl[CG_POS] - com.x, sl[CG_POS + 1] - com.y, sl[CG_POS + 2] - com.z};
+                const V3 tau = cross(off, F);
+                const double pr = (cdof[0] * tau.x + cdof[1] * tau.y + cdof[2] * tau.z) +
+                                  (cdof[3] * F.x + cdof[4] * F.y + cdof[5] * F.z);
+                qc += sgn > 0 ? pr : -pr;
+              }
+            }
+          }
+        }
+        return qc;
+      };
+      // dense Newton direction: H = (tree-sparse part Hr) + sum over contacts U C U^T with
+      // U = J rows of (normal, tangent1, tangent2) and C the 3x3 block of the active pyramid rows;
+      // packed lower triangle in LDS, row = body lane; factorised from the last lane upwards
+      // (H = L^T L, the elimination order of mj_factorM, so the tree part creates no fill-in)
+      auto con_newton_dir = [&](const TpRow& Hr, const double* cj, double g) -> double {
+        double xres = 0;
+        if constexpr (CON) {
+          const int n = m.nbody, ntri = n * (n + 1) / 2;
+          for (int q = l; q < ntri; q += TP_LPE) Hs[q] = 0;
+          bool hasact = false;
+          if (cnr > 0) {
+            const double a0 = cj[0] < 0 ? 1.0 : 0.0, a1 = cj[1] < 0 ? 1.0 : 0.0, a2 = cj[2] < 0 ? 1.0 : 0.0,
+                         a3 = cj[3] < 0 ? 1.0 : 0.0;
+            const double Dm = cDrow * cmu;
+            myslot[CG_C] = cDrow * ((a0 + a1) + (a2 + a3));
+            myslot[CG_C + 1] = Dm * (a0 - a1);
+            myslot[CG_C + 2] = Dm * (a2 - a3);
+            myslot[CG_C + 3] = Dm * cmu * (a0 + a1);
+            myslot[CG_C + 4] = Dm * cmu * (a2 + a3);
+            hasact = (a0 + a1) + (a2 + a3) > 0;
+          }
+          const unsigned long long ab = __ballot(hasact);
+          tp_wave_sync();
+          const tp_lds_d Hrow = Hs + l * (l + 1) / 2;
+          if (l < n) {
+            Hrow[l] = Hr.r[0];
+#pragma unroll
+            for (int a = 1; a < TP_MAXD; a++)
+              if (a < c.dd) Hrow[(c.anc_sa[a] >> 2) & (TP_LPE - 1)] = Hr.r[a];
+          }
+          tp_wave_sync();
+          const unsigned mine = (unsigned)(ab >> base);
+          unsigned merged = (unsigned)(ab | (ab >> 32));
+          while (merged) {
+            const int ci = __builtin_ctz(merged);
+            merged &= merged - 1;
+            const tp_lds_d sl = slot0 + ci * TPC_SLOT;
+            double u0 = 0, u1 = 0, u2 = 0;
+            unsigned chain = 0;
+            if ((mine >> ci) & 1) {
+              const int m1 = ((tp_lds_i)(sl + CG_MASK))[0], m2 = ((tp_lds_i)(sl + CG_MASK))[1];
+              const int sgn = ((m2 >> l) & 1) - ((m1 >> l) & 1);
+              if (sgn != 0) {
+                chain = (unsigned)(m1 ^ m2) & ((2u << l) - 1u);
+                const V3 off = {sl[CG_POS] - com.x, sl[CG_POS + 1] - com.y, sl[CG_POS + 2] - com.z};
+                const V3 w = cross(V3{cdof[0], cdof[1], cdof[2]}, off);
+                const V3 v = {cdof[3] + w.x, cdof[4] + w.y, cdof[5] + w.z};
+                const tp_lds_d f = sl + CG_FRAME;
+                const double sg = sgn > 0 ? 1.0 : -1.0;
+                u0 = sg * (f[0] * v.x + f[1] * v.y + f[2] * v.z);
+                u1 = sg * (f[3] * v.x + f[4] * v.y + f[5] * v.z);
+                u2 = sg * (f[6] * v.x + f[7] * v.y + f[8] * v.z);
+              }
+            }
+            Us[3 * l] = u0; Us[3 * l + 1] = u1; Us[3 * l + 2] = u2;
+            tp_wave_sync();
+            if (chain) {
+              const double v0 = sl[CG_C] * u0 + sl[CG_C + 1] * u1 + sl[CG_C + 2] * u2;
+              const double v1 = sl[CG_C + 1] * u0 + sl[CG_C + 3] * u1;
+              const double v2 = sl[CG_C + 2] * u0 + sl[CG_C + 4] * u2;
+              while (chain) {
+                const int k = __builtin_ctz(chain);
+                chain &= chain - 1;
+                Hrow[k] += v0 * Us[3 * k] + v1 * Us[3 * k + 1] + v2 * Us[3 * k + 2];
+              }
+            }
+            tp_wave_sync();
+          }
+          // factor: for j = n-1 .. 0  L(j,i) = H(j,i) / sqrt(H(j,j)),  H(i,k) -= L(j,i) L(j,k);
+          // the diagonal keeps 1 / L(j,j)
+          for (int jj = n - 1; jj >= 0; jj--) {
+            const tp_lds_d Hj = Hs + jj * (jj + 1) / 2;
+            double dg = Hj[jj];
+            if (dg < BS_MINVAL) dg = BS_MINVAL;
+            const double inv = 1.0 / sqrt(dg);
+            double Lji = 0;
+            if (l < jj) Lji = Hj[l] * inv;
+            tp_wave_sync();
+            if (l < jj) Hj[l] = Lji;
+            if (l == jj) Hj[jj] = inv;
+            tp_wave_sync();
+            if (Lji != 0)
+              for (int k = 0; k <= l; k++) Hrow[k] -= Lji * Hj[k];
+            tp_wave_sync();
+          }
+          // L^T y = g (descending), then L x = y (ascending)
+          double acc = 0, y = 0;
+          for (int jj = n - 1; jj >= 0; jj--) {
+            const tp_lds_d Hj = Hs + jj * (jj + 1) / 2;
+            const double yl = (g - acc) * Hj[jj];
+            const double yj = bperm(yl, (base + jj) * 4);
+            if (l == jj) y = yj;
+            if (l < jj) acc += Hj[l] * yj;
+          }
+          acc = 0;
+          for (int k = 0; k < n; k++) {
+            const double xl = (y - acc) * Hs[k * (k + 1) / 2 + k];
+            const double xk = bperm(xl, (base + k) * 4);
+            if (l == k) xres = xk;
+            if (l > k && l < n) acc += Hrow[k] * xk;
+          }
+        }
+        return xres;
+      };
       if (nefc == 0) {  // env-uniform
         qacc = qacc_smooth; qacc_ws = qacc_smooth; solver_iter = 0;
       } else {
         TpSol s;
-        auto residual = [&](double a, double sub, double& jf, double& jl0, double& jl1, double& je) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) { s.cj[q] = 0; s.cv[q] = 0; }
+        auto residual = [&](double a, double sub, double& jf, double& jl0, double& jl1, double& je, double* cjr) {
           const double ao = bperm(a, eq_other_sa);
           jf = a - sub * r.aref_f; jl0 = a - sub * r.aref_l0; jl1 = -a - sub * r.aref_l1;
           je = r.own ? (a - r.ce * ao) - sub * r.aref_e : 0.0;
+          if constexpr (CON) {
+            double u3[3];
+            con_jx(a, u3);
+            con_rows(u3, sub, cjr);
+          }
         };
         // warm start: previous acceleration only if cheaper than the unconstrained one
         // (M qacc_smooth == qfrc_smooth, so its Gauss term vanishes and Ma is known)
@@ -716,29 +1051,36 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
         double Ma_ws = 0;
         if (!(m.disableflags & BS_DSBL_WARMSTART)) {
           Ma_ws = tp_mul_m(c, Mr, qacc_ws);
-          double jf, jl0, jl1, je;
-          residual(qacc_ws, 1.0, jf, jl0, jl1, je);
-          const double cw = env_sum(tp_rows_cost<false>(r, jf, jl0, jl1, je, nullptr) +
-                                    0.5 * (Ma_ws - qfrc_smooth) * (qacc_ws - qacc_smooth));
-          residual(qacc_smooth, 1.0, jf, jl0, jl1, je);
-          const double cs = env_sum(tp_rows_cost<false>(r, jf, jl0, jl1, je, nullptr));
+          double jf, jl0, jl1, je, cjt[4] = {0, 0, 0, 0};
+          residual(qacc_ws, 1.0, jf, jl0, jl1, je, cjt);
+          double cl = tp_rows_cost<false>(r, jf, jl0, jl1, je, nullptr) +
+                      0.5 * (Ma_ws - qfrc_smooth) * (qacc_ws - qacc_smooth);
+          if constexpr (CON) cl += tp_con_cost<false>(r.cD, cjt, nullptr);
+          const double cw = env_sum(cl);
+          residual(qacc_smooth, 1.0, jf, jl0, jl1, je, cjt);
+          cl = tp_rows_cost<false>(r, jf, jl0, jl1, je, nullptr);
+          if constexpr (CON) cl += tp_con_cost<false>(r.cD, cjt, nullptr);
+          const double cs = env_sum(cl);
           use_smooth = cw > cs;
         }
         s.qacc = has_dof ? (use_smooth ? qacc_smooth : qacc_ws) : 0.0;
         s.Ma = use_smooth ? qfrc_smooth : Ma_ws;
-        residual(s.qacc, 1.0, s.jf, s.jl0, s.jl1, s.je);
+        residual(s.qacc, 1.0, s.jf, s.jl0, s.jl1, s.je, s.cj);
         double gauss = 0, cost = 0, oldcost = 0;
         int iter = 0;
         bool first = true;
         while (true) {
           // constraint update: forces, cost, qfrc_constraint = J^T f, gradient
-          const double cr = tp_rows_cost<true>(r, s.jf, s.jl0, s.jl1, s.je, frc);
+          double cf[4] = {0, 0, 0, 0};
+          double cr = tp_rows_cost<true>(r, s.jf, s.jl0, s.jl1, s.je, frc);
+          if constexpr (CON) cr += tp_con_cost<true>(r.cD, s.cj, cf);
           gauss = env_sum(0.5 * (s.Ma - qfrc_smooth) * (s.qacc - qacc_smooth));
           cost = gauss + env_sum(cr);
           {
             const double fo = bperm(frc[3], eq_src_sa);
             qfrc_constraint = frc[0] + frc[1] - frc[2] + frc[3];
             if (is_src) qfrc_constraint -= r.ce_o * fo;
+            if constexpr (CON) qfrc_constraint += con_jtf(cf);
             if (!has_dof) qfrc_constraint = 0;
           }
           s.grad = s.Ma - qfrc_smooth - qfrc_constraint;
@@ -750,7 +1092,7 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
           }
           first = false;
           if (iter >= m.iterations) break;
-          // H = M + J^T D_active J on the dof-tree sparsity, Newton direction
+          // H = M + J^T D_active J: without contacts it keeps the dof-tree sparsity
           TpRow Hr = Mr;
           if (has_dof) {
             double add = 0;
@@ -766,14 +1108,22 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
             if (is_src) add += r.De_o * r.ce_o * r.ce_o;
             Hr.r[0] += add;
           }
-          const TpFac LH = tp_factor(c, Hr);
-          s.search = has_dof ? -tp_solve(c, LH.R, LH.dinv, s.grad) : 0.0;
+          if constexpr (CON) {
+            const double x = con_newton_dir(Hr, s.cj, has_dof ? s.grad : 0.0);
+            s.search = has_dof ? -x : 0.0;
+          } else {
+            const TpFac LH = tp_factor(c, Hr);
+            s.search = has_dof ? -tp_solve(c, LH.R, LH.dinv, s.grad) : 0.0;
+          }
           s.Mv = tp_mul_m(c, Mr, s.search);
-          residual(s.search, 0.0, s.vf, s.vl0, s.vl1, s.ve);
-          const double alpha = tp_line_search(m, r, s, gauss, scale, qfrc_smooth);
+          residual(s.search, 0.0, s.vf, s.vl0, s.vl1, s.ve, s.cv);
+          const double alpha = tp_line_search<CON>(m, r, s, gauss, scale, qfrc_smooth);
           if (alpha == 0) break;
           s.qacc += alpha * s.search; s.Ma += alpha * s.Mv;
           s.jf += alpha * s.vf; s.jl0 += alpha * s.vl0; s.jl1 += alpha * s.vl1; s.je += alpha * s.ve;
+          if constexpr (CON)
+#pragma unroll
+            for (int q = 0; q < 4; q++) s.cj[q] += alpha * s.cv[q];
           oldcost = cost;
         }
         solver_iter = iter;
@@ -784,6 +1134,7 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
 
       if (mode == 0 && stage == 0 && !redone && env_any(has_dof && bad_num(qacc), base)) {  // mj_checkAcc
         reset_state(); warning |= 4;
+        if constexpr (CON) break;  // contacts belong to the old pose: the next step recomputes everything
         rk_q0 = qpos; rk_v0 = qvel; rk_t0 = time;
         redone = true; stage = -1;
         continue;

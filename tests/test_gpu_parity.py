@@ -246,6 +246,52 @@ def test_contact_sets_exact(hand_model):
     assert st["narrow_pairs"] > 0 and st["contacts"] == int(ncon.sum())
 
 
+def test_contact_step_tree_parallel(hand_model, monkeypatch):
+    """bs_step with contacts runs the tree-parallel kernel (k_tpc): one and three steps against the
+    oracle (qacc <= 1e-8, equal contact sets / nefc), and against the serial contact kernel."""
+    import torch
+    from mujoco_amd import BatchSim, workload
+    m = _contact_model(hand_model)
+    E = 131  # ragged: last wavefront half empty
+    q, v = workload.config2_state(m, E, seed=4242)
+    c = workload.config2_ctrl(m, E, seed=4242)
+    out = {}
+    for kernel in ("tp", "serial"):
+        monkeypatch.setenv("BS_KERNEL", kernel)
+        for nstep in (1, 3):
+            sim = BatchSim(m, n_envs=E)
+            sim.data.qpos.copy_(torch.as_tensor(q))
+            sim.data.qvel.copy_(torch.as_tensor(v))
+            sim.data.ctrl.copy_(torch.as_tensor(c))
+            sim.step(nstep)
+            sim.sync()
+            out[kernel, nstep] = {k: getattr(sim.data, k).cpu().numpy().copy()
+                                  for k in ("qpos", "qvel", "qacc", "ncon", "nefc", "solver_iter", "warning",
+                                            "qfrc_constraint")}
+            out[kernel, nstep]["contacts"] = [sorted((g1, g2) for g1, g2, _ in sim.data.contacts(e)) for e in range(0, E, 5)]
+            del sim
+    monkeypatch.delenv("BS_KERNEL")
+    for nstep in (1, 3):
+        a, b = out["tp", nstep], out["serial", nstep]
+        assert a["ncon"].sum() > 100
+        assert (a["warning"] == 0).all()
+        assert (a["ncon"] == b["ncon"]).all() and (a["nefc"] == b["nefc"]).all()
+        assert a["contacts"] == b["contacts"]
+        sc = np.maximum(1.0, np.abs(b["qacc"]).max(axis=1, keepdims=True))
+        assert (np.abs(a["qacc"] - b["qacc"]) / sc).max() < 1e-8
+        assert np.abs(a["qpos"] - b["qpos"]).max() < 1e-10 and np.abs(a["qvel"] - b["qvel"]).max() < 1e-8
+    for e in range(0, E, 5):
+        for nstep in (1, 3):
+            ref, s = _oracle_forward(m, q[e], v[e], c[e], ["qacc", "qpos", "qvel"], steps=nstep)
+            a = out["tp", nstep]
+            assert a["contacts"][e // 5] == sorted((cc["geom1"], cc["geom2"]) for cc in s.contacts()), (e, nstep)
+            assert a["ncon"][e] == s.ncon and a["nefc"][e] == s.nefc
+            err = np.abs(a["qacc"][e] - ref["qacc"]).max() / max(1.0, np.abs(ref["qacc"]).max())
+            assert err < 1e-8, (e, nstep, err)
+            assert np.abs(a["qpos"][e] - ref["qpos"]).max() < 1e-10
+            assert np.abs(a["qvel"][e] - ref["qvel"]).max() < 1e-8
+
+
 def test_contact_trajectory(hand_model):
     """200 steps with contacts: the trajectory follows the oracle while contact sets agree."""
     import torch
