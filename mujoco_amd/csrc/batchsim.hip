@@ -479,6 +479,30 @@ static int model_image(bs_model* m, int device, const DeviceImage** out) {
     }
   }
   PUT_CI(hull_start, hstart.data(), hstart.size());
+  // neighbour coordinates in adjacency order
+  std::vector<double> nbr((size_t)(s.nhulladj > 0 ? s.nhulladj : 1) * 3, 0.0);
+  for (int me = 0; me < s.nmesh; me++) {
+    const int va = s.mesh_vertadr[me];
+    for (int v = 0; v < s.mesh_vertnum[me]; v++)
+      for (int k = s.hull_adj_start[va + v]; k < s.hull_adj_start[va + v + 1]; k++)
+        for (int q = 0; q < 3; q++) nbr[3 * (size_t)k + q] = s.hull_vert[3 * ((size_t)va + s.hull_adj[k]) + q];
+  }
+  PUT_CD(hull_nbr, nbr.data(), nbr.size());
+  // box around each mesh geom's hull in the geom frame (broadphase separating-axis filter)
+  std::vector<double> obb((size_t)(ng > 0 ? ng : 1) * 6, -1.0);
+  for (int g = 0; g < ng; g++) {
+    const int me = s.geom_dataid[g];
+    if (s.geom_type[g] != BS_GEOM_MESH || me < 0 || me >= s.nmesh || s.mesh_vertnum[me] < 1) continue;
+    const double* V = s.hull_vert + 3 * (size_t)s.mesh_vertadr[me];
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (int v = 0; v < s.mesh_vertnum[me]; v++)
+      for (int k = 0; k < 3; k++) {
+        lo[k] = V[3 * v + k] < lo[k] ? V[3 * v + k] : lo[k];
+        hi[k] = V[3 * v + k] > hi[k] ? V[3 * v + k] : hi[k];
+      }
+    for (int k = 0; k < 3; k++) { obb[6 * g + k] = 0.5 * (lo[k] + hi[k]); obb[6 * g + 3 + k] = 0.5 * (hi[k] - lo[k]); }
+  }
+  PUT_CD(geom_obb, obb.data(), obb.size());
 #undef PUT_CI
 #undef PUT_CD
   TpModel tp = m->tp;

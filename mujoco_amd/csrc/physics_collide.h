@@ -25,10 +25,12 @@ struct ColModel {
       *geom_solmix, *hull_vert;
   const int *mesh_vertadr, *hull_adj_start, *hull_adj;
   const int *hull_start;  // [nmesh][BS_NSTART] support vertex for a cube-map of directions (climb warm start)
+  const double *hull_nbr; // [nhulladj][3] coordinates of the vertex hull_adj[k] names (neighbour scans without a dependent load)
+  const double *geom_obb; // [ngeom][6] box around the hull in the geom frame: centre, half extents (< 0: none)
 };
 
 // cube-map direction bins: 6 faces x BS_SG x BS_SG
-#define BS_SG 4
+#define BS_SG 16
 #define BS_NSTART (6 * BS_SG * BS_SG)
 __host__ __device__ inline int dir_bin(double x, double y, double z) {
   const double ax = x < 0 ? -x : x, ay = y < 0 ? -y : y, az = z < 0 ? -z : z;
@@ -84,7 +86,7 @@ __device__ __forceinline__ bool v_eq(const V3& a, const V3& b) {
 }
 
 struct CObj {
-  const double* vert;
+  const double *vert, *nbr;
   const int *adj_start, *adj, *start;
   int vertadr, cache;
   V3 xpos;
@@ -98,28 +100,38 @@ __device__ inline V3 hull_support(CObj& o, const V3& dir) {
   const V3 d = {R.a[0] * dir.x + R.a[3] * dir.y + R.a[6] * dir.z, R.a[1] * dir.x + R.a[4] * dir.y + R.a[7] * dir.z,
                 R.a[2] * dir.x + R.a[5] * dir.y + R.a[8] * dir.z};
   int imax = o.cache, prev = -1;
-  const double* v0 = o.vert + 3 * imax;
-  double vmax = v0[0] * d.x + v0[1] * d.y + v0[2] * d.z;
+  V3 best = ld3(o.vert + 3 * imax);
+  double vmax = best.x * d.x + best.y * d.y + best.z * d.z;
   {  // better of (previous support vertex, table vertex for this direction bin) as the start
     const int t = o.start[dir_bin(d.x, d.y, d.z)];
-    const double* vt = o.vert + 3 * t;
-    const double val = vt[0] * d.x + vt[1] * d.y + vt[2] * d.z;
-    if (val > vmax) { vmax = val; imax = t; }
+    const V3 vt = ld3(o.vert + 3 * t);
+    const double val = vt.x * d.x + vt.y * d.y + vt.z * d.z;
+    if (val > vmax) { vmax = val; imax = t; best = vt; }
   }
+  // steepest ascent over the hull's vertex adjacency; neighbour coordinates are stored in
+  // adjacency order, four loaded at a time so the loads overlap
   while (imax != prev) {
     prev = imax;
     const int g = o.vertadr + prev;
-    const int k1 = o.adj_start[g + 1];
-    for (int k = o.adj_start[g]; k < k1; k++) {
-      const int nb = o.adj[k];
-      const double* v = o.vert + 3 * nb;
-      const double val = v[0] * d.x + v[1] * d.y + v[2] * d.z;
-      if (val > vmax) { vmax = val; imax = nb; }
+    const int k0 = o.adj_start[g], k1 = o.adj_start[g + 1];
+    for (int k = k0; k < k1; k += 4) {
+      V3 p[4];
+      int id[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int kk = k + q < k1 ? k + q : k1 - 1;
+        p[q] = ld3(o.nbr + 3 * (size_t)kk);
+        id[q] = o.adj[kk];
+      }
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const double val = p[q].x * d.x + p[q].y * d.y + p[q].z * d.z;
+        if (val > vmax) { vmax = val; imax = id[q]; best = p[q]; }
+      }
     }
   }
   o.cache = imax;
-  const V3 v = ld3(o.vert + 3 * imax);
-  const V3 w = mrot(R, v);
+  const V3 w = mrot(R, best);
   return {o.xpos.x + w.x + o.margin * dir.x, o.xpos.y + w.y + o.margin * dir.y, o.xpos.z + w.z + o.margin * dir.z};
 }
 __device__ inline Spt md_support(CObj& a, CObj& b, const V3& dir) {
@@ -290,6 +302,48 @@ __device__ inline void col_geom_frames(const DevModel& m, const DevData& d, cons
   }
 }
 
+// conservative oriented-box filter (15-axis separating-axis test) between the hull boxes of two
+// mesh geoms, each inflated by margin/2: true only if the inflated hulls cannot touch.  It removes
+// narrowphase work only; the contact set is the narrowphase's either way.
+__device__ inline bool obb_separated(const ColModel& cm, const DevData& d, const ColData& c, long e, int g1, int g2,
+                                     const V3& x1, const V3& x2, double margin) {
+  const long E = d.E;
+  double A[9], B[9];
+  for (int k = 0; k < 9; k++) { A[k] = AT(c.geom_xmat, 9 * g1 + k); B[k] = AT(c.geom_xmat, 9 * g2 + k); }
+  const double* oa = cm.geom_obb + 6 * g1;
+  const double* ob = cm.geom_obb + 6 * g2;
+  const double infl = 0.5 * margin + 1e-9;
+  const double ha[3] = {oa[3] + infl, oa[4] + infl, oa[5] + infl}, hb[3] = {ob[3] + infl, ob[4] + infl, ob[5] + infl};
+  // world centres and their difference in A's frame (columns of the geom matrices are the box axes)
+  const V3 ca = {x1.x + A[0] * oa[0] + A[1] * oa[1] + A[2] * oa[2], x1.y + A[3] * oa[0] + A[4] * oa[1] + A[5] * oa[2],
+                 x1.z + A[6] * oa[0] + A[7] * oa[1] + A[8] * oa[2]};
+  const V3 cb = {x2.x + B[0] * ob[0] + B[1] * ob[1] + B[2] * ob[2], x2.y + B[3] * ob[0] + B[4] * ob[1] + B[5] * ob[2],
+                 x2.z + B[6] * ob[0] + B[7] * ob[1] + B[8] * ob[2]};
+  const V3 tw = sub(cb, ca);
+  double R[3][3], Q[3][3], t[3];
+  for (int i = 0; i < 3; i++) {
+    t[i] = tw.x * A[i] + tw.y * A[3 + i] + tw.z * A[6 + i];
+    for (int j = 0; j < 3; j++) {
+      R[i][j] = A[i] * B[j] + A[3 + i] * B[3 + j] + A[6 + i] * B[6 + j];
+      Q[i][j] = fabs(R[i][j]) + 1e-9;
+    }
+  }
+  for (int i = 0; i < 3; i++)
+    if (fabs(t[i]) > ha[i] + hb[0] * Q[i][0] + hb[1] * Q[i][1] + hb[2] * Q[i][2]) return true;
+  for (int j = 0; j < 3; j++)
+    if (fabs(t[0] * R[0][j] + t[1] * R[1][j] + t[2] * R[2][j]) > hb[j] + ha[0] * Q[0][j] + ha[1] * Q[1][j] + ha[2] * Q[2][j])
+      return true;
+  for (int i = 0; i < 3; i++) {
+    const int i1 = (i + 1) % 3, i2 = (i + 2) % 3;
+    for (int j = 0; j < 3; j++) {
+      const int j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+      const double ra = ha[i1] * Q[i2][j] + ha[i2] * Q[i1][j], rb = hb[j1] * Q[i][j2] + hb[j2] * Q[i][j1];
+      if (fabs(t[i2] * R[i1][j] - t[i1] * R[i2][j]) > ra + rb) return true;
+    }
+  }
+  return false;
+}
+
 // A5: one 64-lane wavefront per environment; ordered compaction with ballot + popcount
 __device__ inline void col_broadphase(const ColModel& cm, const DevData& d, const ColData& c, long e, int lane) {
   const long E = d.E;
@@ -307,6 +361,8 @@ __device__ inline void col_broadphase(const ColModel& cm, const DevData& d, cons
       if (r1 > 0 && r2 > 0) {
         const V3 df = sub(x1, x2);
         keep = !(sqrt(dot(df, df)) > margin + r1 + r2);
+        if (keep && cm.geom_obb[6 * g1 + 3] >= 0 && cm.geom_obb[6 * g2 + 3] >= 0)
+          keep = !obb_separated(cm, d, c, e, g1, g2, x1, x2, margin);
       } else if (cm.geom_type[g1] == BS_GEOM_PLANE && r2 > 0) {
         const V3 n = {AT(c.geom_xmat, 9 * g1 + 2), AT(c.geom_xmat, 9 * g1 + 5), AT(c.geom_xmat, 9 * g1 + 8)};
         keep = !(dot(sub(x2, x1), n) > margin + r2);
@@ -337,7 +393,7 @@ __device__ inline void col_narrowphase(const ColModel& cm, const DevData& d, con
     const int mesh = cm.geom_dataid[g2];
     b.vertadr = cm.mesh_vertadr[mesh];
     b.vert = cm.hull_vert + 3 * (size_t)b.vertadr;
-    b.adj_start = cm.hull_adj_start; b.adj = cm.hull_adj; b.cache = 0;
+    b.adj_start = cm.hull_adj_start; b.adj = cm.hull_adj; b.cache = 0; b.nbr = cm.hull_nbr;
     b.start = cm.hull_start + (size_t)mesh * BS_NSTART;
     b.xpos = {AT(c.geom_xpos, 3 * g2), AT(c.geom_xpos, 3 * g2 + 1), AT(c.geom_xpos, 3 * g2 + 2)};
     for (int k = 0; k < 9; k++) b.R.a[k] = AT(c.geom_xmat, 9 * g2 + k);
@@ -360,7 +416,7 @@ __device__ inline void col_narrowphase(const ColModel& cm, const DevData& d, con
     const int mesh = cm.geom_dataid[g1];
     a.vertadr = cm.mesh_vertadr[mesh];
     a.vert = cm.hull_vert + 3 * (size_t)a.vertadr;
-    a.adj_start = cm.hull_adj_start; a.adj = cm.hull_adj; a.cache = 0;
+    a.adj_start = cm.hull_adj_start; a.adj = cm.hull_adj; a.cache = 0; a.nbr = cm.hull_nbr;
     a.start = cm.hull_start + (size_t)mesh * BS_NSTART;
     a.xpos = {AT(c.geom_xpos, 3 * g1), AT(c.geom_xpos, 3 * g1 + 1), AT(c.geom_xpos, 3 * g1 + 2)};
     for (int k = 0; k < 9; k++) a.R.a[k] = AT(c.geom_xmat, 9 * g1 + k);
