@@ -564,20 +564,23 @@ __global__ __launch_bounds__(BS_BLOCK) void k_step(DevModel m, DevData d, int ns
 }
 // tree-parallel kernel: 2 environments per 64-lane block (physics_tp.h)
 __global__ __launch_bounds__(64, 2) void k_tp(DevModel m, TpModel t, DevData d, int nsteps, int mode, int dump) {
-  __shared__ int tbl[TPI_TOTAL * 64];
+  __shared__ int tbl[TPL_TOTAL * 64];
   const TpShared sh = {tbl, nullptr, nullptr, nullptr};
   ColModel cm;
   ColData cd;
   tp_run<false>(m, t, d, nsteps, mode, dump, sh, cm, cd);
 }
 // tree-parallel step with contacts: candidates from k_c_broad / k_c_narrow, one step per launch
-__global__ __launch_bounds__(64, 1) void k_tpc(DevModel m, TpModel t, DevData d, ColModel cm, ColData cd, int mode,
+#ifndef TPC_OCC
+#define TPC_OCC 1
+#endif
+__global__ __launch_bounds__(64, TPC_OCC) void k_tpc(DevModel m, TpModel t, DevData d, ColModel cm, ColData cd, int mode,
                                                int dump) {
-  __shared__ int tbl[TPI_TOTAL * 64];
-  __shared__ double hH[2 * TPC_HTRI];
-  __shared__ double cg[2 * TP_LPE * TPC_SLOT];
-  __shared__ double U[2 * TP_LPE * 3];
-  const TpShared sh = {tbl, hH, cg, U};
+  // dynamic LDS: packed Hessians for nbody rows (2 envs), then contact slots, then the U staging rows
+  __shared__ int tbl[TPL_TOTAL * 64];
+  extern __shared__ double tpc_dyn[];
+  const int ntri = m.nbody * (m.nbody + 1) / 2;
+  const TpShared sh = {tbl, tpc_dyn, tpc_dyn + 2 * ntri, tpc_dyn + 2 * ntri + 2 * TP_LPE * TPC_SLOT};
   tp_run<true>(m, t, d, 1, mode, dump, sh, cm, cd);
 }
 __global__ __launch_bounds__(BS_BLOCK) void k_forward(DevModel m, DevData d) {
@@ -679,13 +682,15 @@ __global__ __launch_bounds__(BS_BLOCK) void k_c_dyn(DevModel m, ColModel cm, Dev
 
 static inline dim3 grid_for(const bs_sim* s) { return dim3((unsigned)((s->n_envs + BS_BLOCK - 1) / BS_BLOCK)); }
 static inline dim3 grid_tp(const bs_sim* s) { return dim3((unsigned)((s->n_envs + 1) / 2)); }
-static void launch_contact_pass(bs_sim* s, int check, int integrate) {
+static void launch_contact_pass(bs_sim* s, int check, int integrate, int dump = 1) {
   const dim3 g = dim3((unsigned)((s->n_envs + BS_BLOCK - 1) / BS_BLOCK));
   hipLaunchKernelGGL(k_c_pos, g, dim3(BS_BLOCK), 0, s->stream, s->dm, s->dd, s->cd, check);
   hipLaunchKernelGGL(k_c_broad, dim3((unsigned)s->n_envs), dim3(64), 0, s->stream, s->cm, s->dd, s->cd);
   hipLaunchKernelGGL(k_c_narrow, dim3(g.x, (unsigned)s->cm.maxcand), dim3(BS_BLOCK), 0, s->stream, s->cm, s->dd, s->cd);
   if (s->use_tpc && integrate) {
-    hipLaunchKernelGGL(k_tpc, grid_tp(s), dim3(64), 0, s->stream, s->dm, s->tp, s->dd, s->cm, s->cd, 0, 1);
+    const int ntri = s->dm.nbody * (s->dm.nbody + 1) / 2;
+    const size_t lds = (size_t)(2 * ntri + 2 * TP_LPE * TPC_SLOT + 2 * TP_LPE * 3) * sizeof(double);
+    hipLaunchKernelGGL(k_tpc, grid_tp(s), dim3(64), lds, s->stream, s->dm, s->tp, s->dd, s->cm, s->cd, 0, dump);
     return;
   }
   hipLaunchKernelGGL(k_c_dyn, g, dim3(BS_BLOCK), s->hs_bytes, s->stream, s->dm, s->cm, s->dd, s->cd, s->kd, integrate,
@@ -693,7 +698,8 @@ static void launch_contact_pass(bs_sim* s, int check, int integrate) {
 }
 static void launch_step(bs_sim* s, int n_steps) {
   if (s->contacts) {
-    for (int k = 0; k < n_steps; k++) launch_contact_pass(s, 1, 1);
+    // outputs of the forward pass (poses, generalized forces) are only observable after the last step
+    for (int k = 0; k < n_steps; k++) launch_contact_pass(s, 1, 1, k == n_steps - 1);
     return;
   }
   if (s->use_tp)
@@ -811,7 +817,7 @@ extern "C" int bs_sim_create(const bs_model* const* models, int n_models, const 
     const size_t mc = (size_t)s->cm.maxcand, mk = (size_t)s->cm.maxcon, nr = 4 * mk, nh = (size_t)nv * (nv + 1) / 2;
     const size_t drows = mc * 7 + mk * 13 + nr * nv + nr * 5 + nh + (model->d.solver == 0 ? nr * nv : 0);
     const size_t irows = 1 + mc * 2 + 1 + mk + 1 + mk;
-    const size_t bytes = drows * E * sizeof(double) + irows * E * sizeof(int) + 64;
+    const size_t bytes = drows * E * sizeof(double) + irows * E * sizeof(int) + 512;
     he = hipMalloc(&s->carena, bytes);
     if (he != hipSuccess) {
       (void)hipFree(s->arena); (void)hipStreamDestroy(s->own_stream);
@@ -1000,6 +1006,16 @@ extern "C" int bs_collision_stats(bs_sim* s, uint64_t out[3], int reset) {
   HIPCHK(hipSetDevice(s->device));
   HIPCHK(hipStreamSynchronize(s->stream));
   HIPCHK(hipMemcpy(out, s->cd.stat, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+#ifdef TPC_PROFILE
+  {
+    uint64_t t[20];
+    HIPCHK(hipMemcpy(t, s->cd.stat + 8, sizeof t, hipMemcpyDeviceToHost));
+    fprintf(stderr, "k_tpc section ticks:");
+    for (int q = 0; q < 20; q++) fprintf(stderr, " [%d] %llu", q, (unsigned long long)t[q]);
+    fprintf(stderr, "\n");
+    if (reset) HIPCHK(hipMemset(s->cd.stat + 8, 0, sizeof t));
+  }
+#endif
   if (reset) HIPCHK(hipMemset(s->cd.stat, 0, 3 * sizeof(uint64_t)));
   return BS_OK;
 }

@@ -38,6 +38,10 @@ enum {
   TPI_TOTAL
 };
 
+// fields kept in LDS (indexed inside loops or by another lane's id); the rest is read once
+// from the table in global memory into registers
+enum { TPL_BCHILD = 0, TPL_DCHILD = TP_MAXC, TPL_ANCMASK = 2 * TP_MAXC, TPL_TOTAL = 2 * TP_MAXC + 1 };
+
 struct TpModel {
   const int* lane;  // [TPI_TOTAL][32]
   int maxdepth, maxdd, nroots;
@@ -94,9 +98,10 @@ typedef int __attribute__((address_space(3))) * tp_lds_i;
 
 // ---- contacts in the tree-parallel layout (k_tpc): contact c of an environment is owned by lane
 // c (so at most 32 contacts); its geometry lives in an LDS slot, its rows in the lane's registers.
-#define TPC_SLOT 21                              // doubles per contact slot (odd stride)
+#define TPC_SLOT 17                              // doubles per contact slot (odd stride)
 #define TPC_HTRI (TP_LPE * (TP_LPE + 1) / 2)     // packed lower-triangular Hessian, one per env
-enum { CG_POS = 0, CG_FRAME = 3, CG_DIST = 12, CG_PAIR = 13, CG_C = 14, CG_MASK = 19 };
+#define TPC_NTRI ((TPC_HTRI + TP_LPE - 1) / TP_LPE)
+enum { CG_POS = 0, CG_FRAME = 3, CG_DIST = 12, CG_PAIR = 13, CG_D = 14, CG_MASK = 15, CG_MU = 16 };  // PAIR: pair id | active rows
 struct TpShared { int* tbl; double* H; double* cg; double* U; };
 // the two environments of a wavefront diverge, so LDS hand-offs between lanes of one environment
 // are ordered with a fence + scheduling barrier instead of s_barrier (LDS is in-order per wave)
@@ -149,7 +154,7 @@ __device__ TP_HELPER_ATTR TpFac tp_factor(TpCtx c, TpRow Rin) {
     if (D == 1) break;
     const bool par = c.dd == D - 1;
     for (int ch = 0; ch < c.nchild[D]; ch++) {
-      const int src = c.tbl[(TPI_DCHILD + ch) * 64 + threadIdx.x];
+      const int src = c.tbl[(TPL_DCHILD + ch) * 64 + threadIdx.x];
       const bool take = par && src >= 0;
       const int sa = src >= 0 ? src : c.self_sa;
 #pragma unroll
@@ -189,7 +194,7 @@ __device__ TP_HELPER_ATTR double tp_solve(TpCtx c, TpRow Rin, double dinv, doubl
     for (int a = 1; a < TP_MAXD; a++)
       if (a < D) T[a] = is ? R[a] * x + W[a] : 0.0;
     for (int ch = 0; ch < c.nchild[D]; ch++) {
-      const int src = c.tbl[(TPI_DCHILD + ch) * 64 + threadIdx.x];
+      const int src = c.tbl[(TPL_DCHILD + ch) * 64 + threadIdx.x];
       const bool take = par && src >= 0;
       const int sa = src >= 0 ? src : c.self_sa;
 #pragma unroll
@@ -240,7 +245,7 @@ __device__ TP_HELPER_ATTR double tp_mul_m(TpCtx c, TpRow Min, double v) {
     for (int a = 1; a < TP_MAXD; a++)
       if (a < D) T[a] = is ? Mr[a] * v + W[a] : 0.0;
     for (int ch = 0; ch < c.nchild[D]; ch++) {
-      const int src = c.tbl[(TPI_DCHILD + ch) * 64 + threadIdx.x];
+      const int src = c.tbl[(TPL_DCHILD + ch) * 64 + threadIdx.x];
       const bool take = par && src >= 0;
       const int sa = src >= 0 ? src : c.self_sa;
 #pragma unroll
@@ -409,6 +414,14 @@ __device__ __forceinline__ double tp_line_search(const DevModel& m, const TpRows
   return best.cost < p0.cost ? best.alpha : 0.0;
 }
 
+// developer profiling (-DTPC_PROFILE): wave-clock ticks per section of k_tpc, summed into
+// ColData::stat[8 + section] by lane 0 of every wavefront
+#ifdef TPC_PROFILE
+#define TPC_T(i) { const unsigned long long now_ = clock64(); tacc[i] += now_ - tlast; tlast = now_; }
+#else
+#define TPC_T(i)
+#endif
+
 // ------------------------------------------------------------------ kernel body
 // mode 0: nsteps x mj_step; mode 1: one mj_forward.  dump 0: state only, 1: + poses and
 // generalized forces of the last forward pass, 2: every intermediate the parity tests read.
@@ -419,41 +432,53 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
                                        int mode, int dump, TpShared sh, const ColModel& cm, const ColData& cd) {
   int* tbl = sh.tbl;
   const int tid = threadIdx.x;
+#ifdef TPC_PROFILE
+  unsigned long long tacc[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = clock64();
+#endif
   const int l = tid & (TP_LPE - 1), base = tid & ~(TP_LPE - 1);
-  // lane table -> LDS; lane references become ds_bpermute byte addresses
-  for (int f = 0; f < TPI_TOTAL; f++) {
-    int v = t.lane[f * TP_LPE + l];
-    const bool is_lane = f == TPI_PARENT || f == TPI_EQ_OTHER || f == TPI_EQ_SRC ||
-                         (f >= TPI_ANC && f < TPI_COUNT);
-    if (is_lane && v >= 0) v = (base + v) * 4;
-    tbl[f * 64 + tid] = v;
-  }
+  // lane table: lane references become ds_bpermute byte addresses; child lists and ancestor
+  // masks go to LDS, everything else straight into registers
+  auto lane_ref = [&](int f) { const int v = t.lane[f * TP_LPE + l]; return v >= 0 ? (base + v) * 4 : v; };
+  for (int f = 0; f < 2 * TP_MAXC; f++) tbl[f * 64 + tid] = lane_ref(TPI_BCHILD + f);
+  tbl[TPL_ANCMASK * 64 + tid] = t.lane[TPI_ANCMASK * TP_LPE + l];
   __syncthreads();
   long env = (long)blockIdx.x * (64 / TP_LPE) + (tid / TP_LPE);
   const bool env_ok = env < d.n_envs;
   if (!env_ok) env = d.n_envs - 1;
   const long E = d.E, e = env;
   const int self_sa = tid * 4;
-  const int par_sa = tbl[TPI_PARENT * 64 + tid];
-  const int depth = tbl[TPI_DEPTH * 64 + tid], jnt = tbl[TPI_JNT * 64 + tid];
-  const int root = tbl[TPI_ROOT * 64 + tid], act = tbl[TPI_ACT * 64 + tid];
-  const int eq_own = tbl[TPI_EQ_OWN * 64 + tid], eq_pos = tbl[TPI_EQ_POS * 64 + tid];
-  const int eq_other_raw = tbl[TPI_EQ_OTHER * 64 + tid], eq_src_raw = tbl[TPI_EQ_SRC * 64 + tid];
+  const int par_sa = lane_ref(TPI_PARENT);
+  const int depth = t.lane[TPI_DEPTH * TP_LPE + l], jnt = t.lane[TPI_JNT * TP_LPE + l];
+  const int root = t.lane[TPI_ROOT * TP_LPE + l], act = t.lane[TPI_ACT * TP_LPE + l];
+  const int eq_own = t.lane[TPI_EQ_OWN * TP_LPE + l], eq_pos = t.lane[TPI_EQ_POS * TP_LPE + l];
+  const int eq_other_raw = lane_ref(TPI_EQ_OTHER), eq_src_raw = lane_ref(TPI_EQ_SRC);
   const int eq_other_sa = eq_other_raw >= 0 ? eq_other_raw : self_sa;
   const int eq_src_sa = eq_src_raw >= 0 ? eq_src_raw : self_sa;
   const bool has_dof = jnt >= 0, is_src = eq_src_raw >= 0;
   const bool isb = l < m.nbody && l > 0;
   const int b = l < m.nbody ? l : 0, j = has_dof ? jnt : 0;
   TpCtx c;
-  c.self_sa = self_sa; c.dd = has_dof ? tbl[TPI_DD * 64 + tid] : 0; c.maxdd = t.maxdd; c.tbl = (tp_lds_ptr)tbl;
+  c.self_sa = self_sa; c.dd = has_dof ? t.lane[TPI_DD * TP_LPE + l] : 0; c.maxdd = t.maxdd; c.tbl = (tp_lds_ptr)tbl;
 #pragma unroll
   for (int a = 0; a < TP_MAXD; a++) {
-    const int v = tbl[(TPI_ANC + a) * 64 + tid];
+    const int v = lane_ref(TPI_ANC + a);
     c.anc_sa[a] = v >= 0 ? v : self_sa;
   }
 #pragma unroll
   for (int D = 0; D < TP_MAXD + 2; D++) c.nchild[D] = t.lvl_dchild[D];
 
+  // packed-triangle coordinates of the entries this lane updates in the dense factorisation
+  int tri_ik[TPC_NTRI];
+  if constexpr (CON) {
+#pragma unroll
+    for (int tt = 0; tt < TPC_NTRI; tt++) {
+      const int q = l + tt * TP_LPE;
+      int i = (int)((sqrtf(8.0f * q + 1.0f) - 1.0f) * 0.5f);
+      if ((i + 1) * (i + 2) / 2 <= q) i++;
+      if (i * (i + 1) / 2 > q) i--;
+      tri_ik[tt] = i | ((q - i * (i + 1) / 2) << 8);
+    }
+  }
   // per-lane model constants
   const V3 bpos = ld3(m.body_pos + 3 * b), jpos = ld3(m.jnt_pos + 3 * j), jax = ld3(m.jnt_axis + 3 * j);
   const Q4 bquat = ld4(m.body_quat + 4 * b);
@@ -475,12 +500,14 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
     solver_iter = 0; nefc = 0; was_reset = true;
   };
 
+  TPC_T(0)
   const int nstage = (mode == 0 && m.integrator == 1) ? 4 : 1;
   for (int step = 0; step < nsteps; step++) {
     if (mode == 0) {  // A14 mj_checkPos / mj_checkVel
       if (env_any(has_dof && bad_num(qpos), base)) { reset_state(); warning |= 1; }
       if (env_any(has_dof && bad_num(qvel), base)) { reset_state(); warning |= 2; }
     }
+    TPC_T(18)
     double rk_q0 = qpos, rk_v0 = qvel, rk_t0 = time, rk_dq = 0, rk_dv = 0;
     bool redone = false;
     for (int stage = 0; stage < nstage; stage++) {
@@ -504,6 +531,7 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
           lp = {bpos.x + dl.x, bpos.y + dl.y, bpos.z + dl.z};
         }
       }
+      TPC_T(19)
       V3 pos = {0, 0, 0};
       Q4 quat = {1, 0, 0, 0};
       for (int lvl = 1; lvl <= t.maxdepth; lvl++) {
@@ -525,6 +553,7 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
         anchor = {pos.x + a.x, pos.y + a.y, pos.z + a.z};
         if (jtype == BS_JNT_SLIDE) { anchor.x -= axis.x * dq; anchor.y -= axis.y * dq; anchor.z -= axis.z * dq; }
       }
+      TPC_T(12)
       // ---- A2 comPos
       V3 xipos;
       {
@@ -583,6 +612,7 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
 #pragma unroll
         for (int k = 0; k < 6; k++) cdof[k] = 0;
       }
+      TPC_T(13)
       // ---- A3 crb (children folded into parents, deepest level first) + mass-matrix rows
       TpRow Mr;
       {
@@ -592,7 +622,7 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
         for (int lvl = t.maxdepth; lvl >= 2; lvl--) {
           const bool par = isb && depth == lvl - 1;
           for (int ch = 0; ch < t.lvl_bchild[lvl]; ch++) {
-            const int src = tbl[(TPI_BCHILD + ch) * 64 + tid];
+            const int src = tbl[(TPL_BCHILD + ch) * 64 + tid];
             const bool take = par && src >= 0;
             const int sa = src >= 0 ? src : self_sa;
 #pragma unroll
@@ -618,8 +648,10 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
           if (a < c.dd) Mr.r[a] = sj;
         }
       }
+      TPC_T(14)
       // ---- A4 factor M
       const TpFac LM = tp_factor(c, Mr);
+      TPC_T(15)
       // ---- A8 comVel + rne bias
       double cvel[6], qfrc_bias;
       {
@@ -649,7 +681,7 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
         for (int lvl = t.maxdepth; lvl >= 2; lvl--) {
           const bool par = isb && depth == lvl - 1;
           for (int ch = 0; ch < t.lvl_bchild[lvl]; ch++) {
-            const int src = tbl[(TPI_BCHILD + ch) * 64 + tid];
+            const int src = tbl[(TPL_BCHILD + ch) * 64 + tid];
             const bool take = par && src >= 0;
             const int sa = src >= 0 ? src : self_sa;
 #pragma unroll
@@ -664,6 +696,7 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
         for (int k = 0; k < 6; k++) s += cdof[k] * f[k];
         qfrc_bias = s;
       }
+      TPC_T(16)
       // ---- passive + A9 actuation + A10 smooth acceleration
       double qfrc_passive = 0, act_force = 0, qfrc_actuator = 0;
       if (has_dof && !(m.disableflags & BS_DSBL_PASSIVE))
@@ -687,6 +720,7 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
       const double qfrc_smooth = has_dof ? qfrc_passive - qfrc_bias + qfrc_applied + qfrc_actuator : 0.0;
       const double qacc_smooth = tp_solve(c, LM.R, LM.dinv, qfrc_smooth);
 
+      TPC_T(1)
       // ---- contacts (k_tpc): ordered hit compaction (same arithmetic as col_assemble) and the
       // pyramid rows of the contact this lane owns (same arithmetic as make_contact_rows)
       const bool con_on = !(m.disableflags & BS_DSBL_CONSTRAINT);
@@ -733,7 +767,7 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
         const int half = tid / TP_LPE;
         slot0 = (tp_lds_d)sh.cg + half * (TP_LPE * TPC_SLOT);
         myslot = slot0 + l * TPC_SLOT;
-        Hs = (tp_lds_d)sh.H + half * TPC_HTRI;
+        Hs = (tp_lds_d)sh.H + half * (m.nbody * (m.nbody + 1) / 2);
         Us = (tp_lds_d)sh.U + half * (TP_LPE * 3);
         const int ncand = AT(cd.ncand, 0);
         int count = 0;
@@ -783,8 +817,8 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
           const int g1 = cm.pair_geom1[pr], g2 = cm.pair_geom2[pr];
           const int b1 = cm.geom_bodyid[g1], b2 = cm.geom_bodyid[g2];
           b1_sa = (base + b1) * 4; b2_sa = (base + b2) * 4;
-          ((tp_lds_i)(myslot + CG_MASK))[0] = tbl[TPI_ANCMASK * 64 + base + b1];
-          ((tp_lds_i)(myslot + CG_MASK))[1] = tbl[TPI_ANCMASK * 64 + base + b2];
+          ((tp_lds_i)(myslot + CG_MASK))[0] = tbl[TPL_ANCMASK * 64 + base + b1];
+          ((tp_lds_i)(myslot + CG_MASK))[1] = tbl[TPL_ANCMASK * 64 + base + b2];
           cpos = {myslot[CG_POS], myslot[CG_POS + 1], myslot[CG_POS + 2]};
           const double margin = fmax(cm.geom_margin[g1], cm.geom_margin[g2]) - fmax(cm.geom_gap[g1], cm.geom_gap[g2]);
           const double dist = myslot[CG_DIST];
@@ -812,6 +846,7 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
               R = fmax(BS_MINVAL, 2 * mue * mue * R);
             }
             cnr = dim == 1 ? 1 : 4; cmu = dim == 1 ? 0.0 : mu; cDrow = 1.0 / R;
+            myslot[CG_D] = cDrow; myslot[CG_MU] = cmu;
             cB = B; ckimp = K * imp * (dist - margin);
           }
         }
@@ -829,6 +864,7 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
         tp_wave_sync();
       }
 
+      TPC_T(2)
       // ---- A7 constraint rows
       TpRows r;
       r.Df = r.rf = r.aref_f = r.fl = 0; r.Dl0 = r.Dl1 = r.aref_l0 = r.aref_l1 = 0;
@@ -938,12 +974,7 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
           if (cnr > 0) {
             const double a0 = cj[0] < 0 ? 1.0 : 0.0, a1 = cj[1] < 0 ? 1.0 : 0.0, a2 = cj[2] < 0 ? 1.0 : 0.0,
                          a3 = cj[3] < 0 ? 1.0 : 0.0;
-            const double Dm = cDrow * cmu;
-            myslot[CG_C] = cDrow * ((a0 + a1) + (a2 + a3));
-            myslot[CG_C + 1] = Dm * (a0 - a1);
-            myslot[CG_C + 2] = Dm * (a2 - a3);
-            myslot[CG_C + 3] = Dm * cmu * (a0 + a1);
-            myslot[CG_C + 4] = Dm * cmu * (a2 + a3);
+            ((tp_lds_i)(myslot + CG_PAIR))[1] = (cj[0] < 0 ? 1 : 0) | (cj[1] < 0 ? 2 : 0) | (cj[2] < 0 ? 4 : 0) | (cj[3] < 0 ? 8 : 0);
             hasact = (a0 + a1) + (a2 + a3) > 0;
           }
           const unsigned long long ab = __ballot(hasact);
@@ -982,9 +1013,15 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
             Us[3 * l] = u0; Us[3 * l + 1] = u1; Us[3 * l + 2] = u2;
             tp_wave_sync();
             if (chain) {
-              const double v0 = sl[CG_C] * u0 + sl[CG_C + 1] * u1 + sl[CG_C + 2] * u2;
-              const double v1 = sl[CG_C + 1] * u0 + sl[CG_C + 3] * u1;
-              const double v2 = sl[CG_C + 2] * u0 + sl[CG_C + 4] * u2;
+              // 3x3 block of the active pyramid rows: rows are n +- mu t1, n +- mu t2, all with weight D
+              const int ab = ((tp_lds_i)(sl + CG_PAIR))[1];
+              const double a0 = ab & 1 ? 1.0 : 0.0, a1 = ab & 2 ? 1.0 : 0.0, a2 = ab & 4 ? 1.0 : 0.0, a3 = ab & 8 ? 1.0 : 0.0;
+              const double Dc = sl[CG_D], muc = sl[CG_MU], Dm = Dc * muc;
+              const double Cnn = Dc * ((a0 + a1) + (a2 + a3)), Cn1 = Dm * (a0 - a1), Cn2 = Dm * (a2 - a3);
+              const double C11 = Dm * muc * (a0 + a1), C22 = Dm * muc * (a2 + a3);
+              const double v0 = Cnn * u0 + Cn1 * u1 + Cn2 * u2;
+              const double v1 = Cn1 * u0 + C11 * u1;
+              const double v2 = Cn2 * u0 + C22 * u2;
               while (chain) {
                 const int k = __builtin_ctz(chain);
                 chain &= chain - 1;
@@ -993,23 +1030,33 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
             }
             tp_wave_sync();
           }
+          TPC_T(6)
           // factor: for j = n-1 .. 0  L(j,i) = H(j,i) / sqrt(H(j,j)),  H(i,k) -= L(j,i) L(j,k);
           // the diagonal keeps 1 / L(j,j)
+          // the update of column jj touches the packed entries q < tri(jj); they are dealt
+          // round-robin to the 32 lanes (entry q = l + 32 t has row/column tri_ik[t])
           for (int jj = n - 1; jj >= 0; jj--) {
-            const tp_lds_d Hj = Hs + jj * (jj + 1) / 2;
+            const int tj = jj * (jj + 1) / 2;
+            const tp_lds_d Hj = Hs + tj;
             double dg = Hj[jj];
             if (dg < BS_MINVAL) dg = BS_MINVAL;
             const double inv = 1.0 / sqrt(dg);
-            double Lji = 0;
-            if (l < jj) Lji = Hj[l] * inv;
-            tp_wave_sync();
+            const double Lji = l < jj ? Hj[l] * inv : 0.0;
             if (l < jj) Hj[l] = Lji;
             if (l == jj) Hj[jj] = inv;
             tp_wave_sync();
-            if (Lji != 0)
-              for (int k = 0; k <= l; k++) Hrow[k] -= Lji * Hj[k];
+#pragma unroll
+            for (int tt = 0; tt < TPC_NTRI; tt++) {
+              if (tt * TP_LPE >= tj) break;
+              const int q = l + tt * TP_LPE;
+              if (q < tj) {
+                const int ik = tri_ik[tt];
+                Hs[q] -= Hj[ik & 0xff] * Hj[ik >> 8];
+              }
+            }
             tp_wave_sync();
           }
+          TPC_T(7)
           // L^T y = g (descending), then L x = y (ascending)
           double acc = 0, y = 0;
           for (int jj = n - 1; jj >= 0; jj--) {
@@ -1026,9 +1073,11 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
             if (l == k) xres = xk;
             if (l > k && l < n) acc += Hrow[k] * xk;
           }
+          TPC_T(8)
         }
         return xres;
       };
+      TPC_T(3)
       if (nefc == 0) {  // env-uniform
         qacc = qacc_smooth; qacc_ws = qacc_smooth; solver_iter = 0;
       } else {
@@ -1069,6 +1118,7 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
         double gauss = 0, cost = 0, oldcost = 0;
         int iter = 0;
         bool first = true;
+        TPC_T(4)
         while (true) {
           // constraint update: forces, cost, qfrc_constraint = J^T f, gradient
           double cf[4] = {0, 0, 0, 0};
@@ -1092,6 +1142,7 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
           }
           first = false;
           if (iter >= m.iterations) break;
+          TPC_T(5)
           // H = M + J^T D_active J: without contacts it keeps the dof-tree sparsity
           TpRow Hr = Mr;
           if (has_dof) {
@@ -1115,6 +1166,7 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
             const TpFac LH = tp_factor(c, Hr);
             s.search = has_dof ? -tp_solve(c, LH.R, LH.dinv, s.grad) : 0.0;
           }
+          TPC_T(9)
           s.Mv = tp_mul_m(c, Mr, s.search);
           residual(s.search, 0.0, s.vf, s.vl0, s.vl1, s.ve, s.cv);
           const double alpha = tp_line_search<CON>(m, r, s, gauss, scale, qfrc_smooth);
@@ -1125,6 +1177,7 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
 #pragma unroll
             for (int q = 0; q < 4; q++) s.cj[q] += alpha * s.cv[q];
           oldcost = cost;
+          TPC_T(10)
         }
         solver_iter = iter;
         qacc = s.qacc;
@@ -1173,13 +1226,14 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
             for (int a = 0; a < TP_MAXD; a++)
               if (a < c.dd) { AT(d.qM, adr + a) = Mr.r[a]; AT(d.qLD, adr + a) = LM.R.r[a]; }
             AT(d.qLDiagInv, j) = LM.dinv;
-            const int fr = tbl[TPI_FRIC_ROW * 64 + tid], lr = tbl[TPI_LIM_ROW * 64 + tid];
+            const int fr = t.lane[TPI_FRIC_ROW * TP_LPE + l], lr = t.lane[TPI_LIM_ROW * TP_LPE + l];
             if (fr >= 0) AT(d.efc_force, fr) = frc[0];
             if (lr >= 0) { AT(d.efc_force, lr) = frc[1]; AT(d.efc_force, lr + 1) = frc[2]; }
             if (eq_own >= 0) AT(d.efc_force, eq_own) = frc[3];
           }
         }
       }
+      TPC_T(17)
       if (mode == 1) break;
       if (nstage == 1) {
         // ---- A12 Euler with implicit joint damping
@@ -1207,6 +1261,13 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
       }
     }
   }
+#ifdef TPC_PROFILE
+  if constexpr (CON) {
+    TPC_T(11)
+    if (tid == 0 && cd.stat)
+      for (int q = 0; q < 20; q++) atomicAdd(cd.stat + 8 + q, tacc[q]);
+  }
+#endif
   if (!env_ok) return;
   if (has_dof) {
     AT(d.qpos, j) = qpos; AT(d.qvel, j) = qvel; AT(d.qacc, j) = qacc; AT(d.qacc_warmstart, j) = qacc_ws;
