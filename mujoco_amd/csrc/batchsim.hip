@@ -570,9 +570,14 @@ __global__ __launch_bounds__(64, 2) void k_tp(DevModel m, TpModel t, DevData d, 
   ColData cd;
   tp_run<false>(m, t, d, nsteps, mode, dump, sh, cm, cd);
 }
+// kinematics + geom frames + broadphase, tree-parallel layout (physics_tp.h::tp_collide_prep)
+__global__ __launch_bounds__(64) void k_tp_col(DevModel m, TpModel t, DevData d, ColModel cm, ColData cd) {
+  extern __shared__ double tpg_dyn[];  // geom frames of the two environments
+  tp_collide_prep(m, t, d, cm, cd, tpg_dyn);
+}
 // tree-parallel step with contacts: candidates from k_c_broad / k_c_narrow, one step per launch
 #ifndef TPC_OCC
-#define TPC_OCC 1
+#define TPC_OCC 2
 #endif
 __global__ __launch_bounds__(64, TPC_OCC) void k_tpc(DevModel m, TpModel t, DevData d, ColModel cm, ColData cd, int mode,
                                                int dump) {
@@ -684,8 +689,13 @@ static inline dim3 grid_for(const bs_sim* s) { return dim3((unsigned)((s->n_envs
 static inline dim3 grid_tp(const bs_sim* s) { return dim3((unsigned)((s->n_envs + 1) / 2)); }
 static void launch_contact_pass(bs_sim* s, int check, int integrate, int dump = 1) {
   const dim3 g = dim3((unsigned)((s->n_envs + BS_BLOCK - 1) / BS_BLOCK));
-  hipLaunchKernelGGL(k_c_pos, g, dim3(BS_BLOCK), 0, s->stream, s->dm, s->dd, s->cd, check);
-  hipLaunchKernelGGL(k_c_broad, dim3((unsigned)s->n_envs), dim3(64), 0, s->stream, s->cm, s->dd, s->cd);
+  if (s->use_tpc && integrate) {
+    const size_t lds = (size_t)2 * s->cm.ngeom * TPG_SLOT * sizeof(double);
+    hipLaunchKernelGGL(k_tp_col, grid_tp(s), dim3(64), lds, s->stream, s->dm, s->tp, s->dd, s->cm, s->cd);
+  } else {
+    hipLaunchKernelGGL(k_c_pos, g, dim3(BS_BLOCK), 0, s->stream, s->dm, s->dd, s->cd, check);
+    hipLaunchKernelGGL(k_c_broad, dim3((unsigned)s->n_envs), dim3(64), 0, s->stream, s->cm, s->dd, s->cd);
+  }
   hipLaunchKernelGGL(k_c_narrow, dim3(g.x, (unsigned)s->cm.maxcand), dim3(BS_BLOCK), 0, s->stream, s->cm, s->dd, s->cd);
   if (s->use_tpc && integrate) {
     const int ntri = s->dm.nbody * (s->dm.nbody + 1) / 2;

@@ -305,13 +305,18 @@ __device__ inline void col_geom_frames(const DevModel& m, const DevData& d, cons
 // conservative oriented-box filter (15-axis separating-axis test) between the hull boxes of two
 // mesh geoms, each inflated by margin/2: true only if the inflated hulls cannot touch.  It removes
 // narrowphase work only; the contact set is the narrowphase's either way.
+__device__ inline bool obb_separated_m(const double* oa, const double* ob, const double* A, const double* B,
+                                       const V3& x1, const V3& x2, double margin);
 __device__ inline bool obb_separated(const ColModel& cm, const DevData& d, const ColData& c, long e, int g1, int g2,
                                      const V3& x1, const V3& x2, double margin) {
   const long E = d.E;
   double A[9], B[9];
   for (int k = 0; k < 9; k++) { A[k] = AT(c.geom_xmat, 9 * g1 + k); B[k] = AT(c.geom_xmat, 9 * g2 + k); }
-  const double* oa = cm.geom_obb + 6 * g1;
-  const double* ob = cm.geom_obb + 6 * g2;
+  return obb_separated_m(cm.geom_obb + 6 * g1, cm.geom_obb + 6 * g2, A, B, x1, x2, margin);
+}
+// oa/ob: box centre + half extents in the geom frame; A/B: geom rotation matrices (row-major)
+__device__ inline bool obb_separated_m(const double* oa, const double* ob, const double* A, const double* B,
+                                       const V3& x1, const V3& x2, double margin) {
   const double infl = 0.5 * margin + 1e-9;
   const double ha[3] = {oa[3] + infl, oa[4] + infl, oa[5] + infl}, hb[3] = {ob[3] + infl, ob[4] + infl, ob[5] + infl};
   // world centres and their difference in A's frame (columns of the geom matrices are the box axes)

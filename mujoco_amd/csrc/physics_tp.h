@@ -414,6 +414,130 @@ __device__ __forceinline__ double tp_line_search(const DevModel& m, const TpRows
   return best.cost < p0.cost ? best.alpha : 0.0;
 }
 
+// ------------------------------------------------------------------ k_tp_col
+// Collision preparation in the tree-parallel layout: kinematics (lane = body, same arithmetic as
+// tp_run's A1), geom frames (lane = geom) and the broadphase (lane = candidate pair, bounding
+// spheres + oriented-box filter, ordered ballot compaction = col_broadphase), two environments
+// per wavefront.  Replaces k_c_pos + k_c_broad when k_tpc runs the dynamics; a state that fails
+// mj_checkPos / mj_checkVel is treated as reset (k_tpc performs the reset itself).
+#define TPG_SLOT 13  // doubles per geom frame in LDS: position, matrix (odd stride)
+__device__ __forceinline__ void tp_collide_prep(const DevModel& m, const TpModel& t, const DevData& d,
+                                                const ColModel& cm, const ColData& cd, double* gfr) {
+  const int tid = threadIdx.x;
+  const int l = tid & (TP_LPE - 1), base = tid & ~(TP_LPE - 1);
+  long env = (long)blockIdx.x * (64 / TP_LPE) + (tid / TP_LPE);
+  const bool env_ok = env < d.n_envs;
+  if (!env_ok) env = d.n_envs - 1;
+  const long E = d.E, e = env;
+  const int self_sa = tid * 4;
+  const int pv = t.lane[TPI_PARENT * TP_LPE + l];
+  const int par_sa = pv >= 0 ? (base + pv) * 4 : self_sa;
+  const int depth = t.lane[TPI_DEPTH * TP_LPE + l], jnt = t.lane[TPI_JNT * TP_LPE + l];
+  const bool has_dof = jnt >= 0, isb = l < m.nbody && l > 0;
+  const int b = l < m.nbody ? l : 0, j = has_dof ? jnt : 0;
+  const V3 bpos = ld3(m.body_pos + 3 * b), jpos = ld3(m.jnt_pos + 3 * j), jax = ld3(m.jnt_axis + 3 * j);
+  const Q4 bquat = ld4(m.body_quat + 4 * b);
+  const int jtype = m.jnt_type[j];
+  const double qpos0 = m.qpos0[j];
+  double qpos = has_dof ? AT(d.qpos, j) : 0.0;
+  const double qvel = has_dof ? AT(d.qvel, j) : 0.0;
+  if (env_any(has_dof && (bad_num(qpos) || bad_num(qvel)), base)) qpos = qpos0;
+  const double dq = qpos - qpos0;
+  Q4 lq = bquat;
+  V3 lp = bpos;
+  if (has_dof) {
+    if (jtype == BS_JNT_SLIDE) {
+      const V3 s = mrot(q2m(bquat), jax);
+      lp = {bpos.x + s.x * dq, bpos.y + s.y * dq, bpos.z + s.z * dq};
+    } else {
+      double sn, cs;
+      sincos(0.5 * dq, &sn, &cs);
+      const Q4 qj = {cs, jax.x * sn, jax.y * sn, jax.z * sn};
+      lq = qmul(bquat, qj);
+      const V3 rj = mrot(q2m(qj), jpos);
+      const V3 dl = mrot(q2m(bquat), V3{jpos.x - rj.x, jpos.y - rj.y, jpos.z - rj.z});
+      lp = {bpos.x + dl.x, bpos.y + dl.y, bpos.z + dl.z};
+    }
+  }
+  V3 pos = {0, 0, 0};
+  Q4 quat = {1, 0, 0, 0};
+  for (int lvl = 1; lvl <= t.maxdepth; lvl++) {
+    const V3 pp = {bperm(pos.x, par_sa), bperm(pos.y, par_sa), bperm(pos.z, par_sa)};
+    const Q4 pq = {bperm(quat.w, par_sa), bperm(quat.x, par_sa), bperm(quat.y, par_sa), bperm(quat.z, par_sa)};
+    if (isb && depth == lvl) {
+      const V3 tt = mrot(q2m(pq), lp);
+      pos = {pp.x + tt.x, pp.y + tt.y, pp.z + tt.z};
+      quat = qmul(pq, lq);
+      const double n2 = quat.w * quat.w + quat.x * quat.x + quat.y * quat.y + quat.z * quat.z;
+      const double inv = 1.0 / sqrt(n2);
+      quat.w *= inv; quat.x *= inv; quat.y *= inv; quat.z *= inv;
+    }
+  }
+  // geom frames: lane = geom (chunks of 32), body pose fetched from the body's lane
+  const tp_lds_d G = (tp_lds_d)gfr + (tid / TP_LPE) * (cm.ngeom * TPG_SLOT);
+  for (int g0 = 0; g0 < cm.ngeom; g0 += TP_LPE) {
+    const int g = g0 + l;
+    const bool live = g < cm.ngeom;
+    const int gb = live ? m.geom_bodyid[g] : 0;
+    const int sa = (base + gb) * 4;
+    const V3 bp = {bperm(pos.x, sa), bperm(pos.y, sa), bperm(pos.z, sa)};
+    const Q4 bq = {bperm(quat.w, sa), bperm(quat.x, sa), bperm(quat.y, sa), bperm(quat.z, sa)};
+    if (live) {
+      const V3 p = mrot(q2m(bq), ld3(m.geom_pos + 3 * g));
+      const M3 R = q2m(qmul(bq, ld4(m.geom_quat + 4 * g)));
+      const double px = bp.x + p.x, py = bp.y + p.y, pz = bp.z + p.z;
+      const tp_lds_d s = G + g * TPG_SLOT;
+      s[0] = px; s[1] = py; s[2] = pz;
+#pragma unroll
+      for (int k = 0; k < 9; k++) s[3 + k] = R.a[k];
+      if (env_ok) {
+        AT(cd.geom_xpos, 3 * g) = px; AT(cd.geom_xpos, 3 * g + 1) = py; AT(cd.geom_xpos, 3 * g + 2) = pz;
+#pragma unroll
+        for (int k = 0; k < 9; k++) AT(cd.geom_xmat, 9 * g + k) = R.a[k];
+      }
+    }
+  }
+  tp_wave_sync();
+  // broadphase over the candidate pairs, in pair order
+  int count = 0;
+  for (int p0 = 0; p0 < cm.npair; p0 += TP_LPE) {
+    const int p = p0 + l;
+    bool keep = false;
+    if (p < cm.npair) {
+      const int g1 = cm.pair_geom1[p], g2 = cm.pair_geom2[p];
+      const int t1 = cm.geom_type[g1], t2 = cm.geom_type[g2];
+      if ((t1 == BS_GEOM_PLANE || t1 == BS_GEOM_MESH) && t2 == BS_GEOM_MESH) {
+        const double margin = fmax(cm.geom_margin[g1], cm.geom_margin[g2]);
+        const double r1 = cm.geom_rbound[g1], r2 = cm.geom_rbound[g2];
+        const tp_lds_d s1 = G + g1 * TPG_SLOT, s2 = G + g2 * TPG_SLOT;
+        const V3 x1 = {s1[0], s1[1], s1[2]}, x2 = {s2[0], s2[1], s2[2]};
+        keep = true;
+        if (r1 > 0 && r2 > 0) {
+          const V3 df = sub(x1, x2);
+          keep = !(sqrt(dot(df, df)) > margin + r1 + r2);
+          if (keep && cm.geom_obb[6 * g1 + 3] >= 0 && cm.geom_obb[6 * g2 + 3] >= 0) {
+            double A[9], B[9];
+#pragma unroll
+            for (int k = 0; k < 9; k++) { A[k] = s1[3 + k]; B[k] = s2[3 + k]; }
+            keep = !obb_separated_m(cm.geom_obb + 6 * g1, cm.geom_obb + 6 * g2, A, B, x1, x2, margin);
+          }
+        } else if (t1 == BS_GEOM_PLANE && r2 > 0) {
+          const V3 n = {s1[3 + 2], s1[3 + 5], s1[3 + 8]};
+          keep = !(dot(sub(x2, x1), n) > margin + r2);
+        }
+      }
+    }
+    const unsigned bits = (unsigned)(__ballot(keep) >> base);
+    const int at = count + __popc(bits & ((1u << l) - 1u));
+    if (keep && at < cm.maxcand && env_ok) AT(cd.cand_pair, at) = p;
+    count += __popc(bits);
+  }
+  if (l == 0 && env_ok) {
+    if (count > cm.maxcand) { count = cm.maxcand; AT(d.warning, 0) |= 8; }
+    AT(cd.ncand, 0) = count;
+  }
+}
+
 // developer profiling (-DTPC_PROFILE): wave-clock ticks per section of k_tpc, summed into
 // ColData::stat[8 + section] by lane 0 of every wavefront
 #ifdef TPC_PROFILE
