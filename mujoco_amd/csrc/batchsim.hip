@@ -172,7 +172,7 @@ namespace {
 struct Packer {
   std::vector<char> bytes;
   size_t add(const void* p, size_t n) {
-    size_t off = (bytes.size() + 15) & ~size_t(15);
+    size_t off = (bytes.size() + 31) & ~size_t(31);  // 32 bytes: double4 records
     bytes.resize(off + (n ? n : 16));
     if (n) memcpy(bytes.data() + off, p, n);
     return off;
@@ -479,15 +479,26 @@ static int model_image(bs_model* m, int device, const DeviceImage** out) {
     }
   }
   PUT_CI(hull_start, hstart.data(), hstart.size());
-  // neighbour coordinates in adjacency order
-  std::vector<double> nbr((size_t)(s.nhulladj > 0 ? s.nhulladj : 1) * 3, 0.0);
+  // hill-climbing records: neighbour {x, y, z, id} per adjacency entry, padded vertices, ranges
+  std::vector<double> nbr4((size_t)(s.nhulladj > 0 ? s.nhulladj : 1) * 4, 0.0);
+  std::vector<double> vert4((size_t)(s.nhullvert > 0 ? s.nhullvert : 1) * 4, 0.0);
+  std::vector<int32_t> range((size_t)(s.nhullvert > 0 ? s.nhullvert : 1) * 2, 0);
   for (int me = 0; me < s.nmesh; me++) {
     const int va = s.mesh_vertadr[me];
-    for (int v = 0; v < s.mesh_vertnum[me]; v++)
-      for (int k = s.hull_adj_start[va + v]; k < s.hull_adj_start[va + v + 1]; k++)
-        for (int q = 0; q < 3; q++) nbr[3 * (size_t)k + q] = s.hull_vert[3 * ((size_t)va + s.hull_adj[k]) + q];
+    for (int v = 0; v < s.mesh_vertnum[me]; v++) {
+      for (int q = 0; q < 3; q++) vert4[4 * ((size_t)va + v) + q] = s.hull_vert[3 * ((size_t)va + v) + q];
+      range[2 * ((size_t)va + v)] = s.hull_adj_start[va + v];
+      range[2 * ((size_t)va + v) + 1] = s.hull_adj_start[va + v + 1];
+      for (int k = s.hull_adj_start[va + v]; k < s.hull_adj_start[va + v + 1]; k++) {
+        for (int q = 0; q < 3; q++) nbr4[4 * (size_t)k + q] = s.hull_vert[3 * ((size_t)va + s.hull_adj[k]) + q];
+        const int64_t bits = (int64_t)(uint32_t)s.hull_adj[k];  // id in the low word of the 4th double
+        memcpy(&nbr4[4 * (size_t)k + 3], &bits, sizeof bits);
+      }
+    }
   }
-  PUT_CD(hull_nbr, nbr.data(), nbr.size());
+  fix.push_back({pk.add(nbr4.data(), nbr4.size() * sizeof(double)), (void**)&cm.hull_nbr4});
+  fix.push_back({pk.add(vert4.data(), vert4.size() * sizeof(double)), (void**)&cm.hull_vert4});
+  fix.push_back({pk.add(range.data(), range.size() * sizeof(int32_t)), (void**)&cm.hull_range});
   // box around each mesh geom's hull in the geom frame (broadphase separating-axis filter)
   std::vector<double> obb((size_t)(ng > 0 ? ng : 1) * 6, -1.0);
   for (int g = 0; g < ng; g++) {
@@ -671,6 +682,37 @@ __global__ __launch_bounds__(BS_BLOCK) void k_c_narrow(ColModel cm, DevData d, C
   if (e >= d.n_envs) return;
   col_narrowphase(cm, d, c, e, blockIdx.y);
 }
+// narrowphase over the flattened (environment, candidate slot) items of NB_ENVS environments:
+// an exclusive scan of the candidate counts in LDS, then every lane takes items round-robin, so
+// no lane idles on environments with few candidates and no wavefront is launched for empty slots
+#define NB_ENVS 64
+#define NB_THREADS 256
+__global__ __launch_bounds__(NB_THREADS) void k_c_narrow_flat(ColModel cm, DevData d, ColData c) {
+  __shared__ int pre[NB_ENVS + 1];
+  const long e0 = (long)blockIdx.x * NB_ENVS;
+  const int tid = threadIdx.x;
+  if (tid < NB_ENVS) {  // first wavefront: inclusive scan of the candidate counts with DPP-free shuffles
+    const long e = e0 + tid, E = d.E;
+    int v = e < d.n_envs ? AT(c.ncand, 0) : 0;
+    for (int off = 1; off < NB_ENVS; off <<= 1) {
+      const int u = __shfl_up(v, off, 64);
+      if (tid >= off) v += u;
+    }
+    pre[tid + 1] = v;
+    if (tid == 0) pre[0] = 0;
+  }
+  __syncthreads();
+  const int total = pre[NB_ENVS];
+  for (int item = tid; item < total; item += NB_THREADS) {
+    int lo = 0, hi = NB_ENVS;  // largest env index with pre[env] <= item
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (pre[mid] <= item) lo = mid;
+      else hi = mid;
+    }
+    col_narrowphase(cm, d, c, e0 + lo, item - pre[lo]);
+  }
+}
 __global__ __launch_bounds__(BS_BLOCK) void k_c_dyn(DevModel m, ColModel cm, DevData d, ColData c, ConData k,
                                                     int integrate, int lds_hessian) {
   extern __shared__ double hs_lds[];  // dense Hessian + one Jacobian row per lane, [entry][64]
@@ -696,7 +738,11 @@ static void launch_contact_pass(bs_sim* s, int check, int integrate, int dump = 
     hipLaunchKernelGGL(k_c_pos, g, dim3(BS_BLOCK), 0, s->stream, s->dm, s->dd, s->cd, check);
     hipLaunchKernelGGL(k_c_broad, dim3((unsigned)s->n_envs), dim3(64), 0, s->stream, s->cm, s->dd, s->cd);
   }
-  hipLaunchKernelGGL(k_c_narrow, dim3(g.x, (unsigned)s->cm.maxcand), dim3(BS_BLOCK), 0, s->stream, s->cm, s->dd, s->cd);
+  if (getenv("BS_NARROW_GRID"))
+    hipLaunchKernelGGL(k_c_narrow, dim3(g.x, (unsigned)s->cm.maxcand), dim3(BS_BLOCK), 0, s->stream, s->cm, s->dd, s->cd);
+  else
+    hipLaunchKernelGGL(k_c_narrow_flat, dim3((unsigned)((s->n_envs + NB_ENVS - 1) / NB_ENVS)), dim3(NB_THREADS), 0, s->stream,
+                       s->cm, s->dd, s->cd);
   if (s->use_tpc && integrate) {
     const int ntri = s->dm.nbody * (s->dm.nbody + 1) / 2;
     const size_t lds = (size_t)(2 * ntri + 2 * TP_LPE * TPC_SLOT + 2 * TP_LPE * 3) * sizeof(double);

@@ -25,7 +25,12 @@ struct ColModel {
       *geom_solmix, *hull_vert;
   const int *mesh_vertadr, *hull_adj_start, *hull_adj;
   const int *hull_start;  // [nmesh][BS_NSTART] support vertex for a cube-map of directions (climb warm start)
-  const double *hull_nbr; // [nhulladj][3] coordinates of the vertex hull_adj[k] names (neighbour scans without a dependent load)
+  // hill-climbing data packed for few, wide loads (divergent 8-byte loads are what bounds the
+  // narrowphase): per adjacency entry {x, y, z, vertex id} of the neighbour, per vertex
+  // {x, y, z, -} and its adjacency range {first, end}
+  const double4 *hull_nbr4;  // [nhulladj]
+  const double4 *hull_vert4; // [nhullvert]
+  const int2 *hull_range;    // [nhullvert]
   const double *geom_obb; // [ngeom][6] box around the hull in the geom frame: centre, half extents (< 0: none)
 };
 
@@ -86,9 +91,10 @@ __device__ __forceinline__ bool v_eq(const V3& a, const V3& b) {
 }
 
 struct CObj {
-  const double *vert, *nbr;
-  const int *adj_start, *adj, *start;
-  int vertadr, cache;
+  const double4 *vert4, *nbr4;  // vert4: this mesh's vertices; nbr4: global adjacency records
+  const int2* range;            // this mesh's vertices
+  const int* start;
+  int cache;
   V3 xpos;
   M3 R;
   double margin;
@@ -100,33 +106,28 @@ __device__ inline V3 hull_support(CObj& o, const V3& dir) {
   const V3 d = {R.a[0] * dir.x + R.a[3] * dir.y + R.a[6] * dir.z, R.a[1] * dir.x + R.a[4] * dir.y + R.a[7] * dir.z,
                 R.a[2] * dir.x + R.a[5] * dir.y + R.a[8] * dir.z};
   int imax = o.cache, prev = -1;
-  V3 best = ld3(o.vert + 3 * imax);
+  const double4 vc = o.vert4[imax];
+  V3 best = {vc.x, vc.y, vc.z};
   double vmax = best.x * d.x + best.y * d.y + best.z * d.z;
   {  // better of (previous support vertex, table vertex for this direction bin) as the start
     const int t = o.start[dir_bin(d.x, d.y, d.z)];
-    const V3 vt = ld3(o.vert + 3 * t);
+    const double4 vt = o.vert4[t];
     const double val = vt.x * d.x + vt.y * d.y + vt.z * d.z;
-    if (val > vmax) { vmax = val; imax = t; best = vt; }
+    if (val > vmax) { vmax = val; imax = t; best = {vt.x, vt.y, vt.z}; }
   }
-  // steepest ascent over the hull's vertex adjacency; neighbour coordinates are stored in
-  // adjacency order, four loaded at a time so the loads overlap
+  // steepest ascent over the hull's vertex adjacency; four neighbour records are loaded at a
+  // time so the loads overlap
   while (imax != prev) {
     prev = imax;
-    const int g = o.vertadr + prev;
-    const int k0 = o.adj_start[g], k1 = o.adj_start[g + 1];
-    for (int k = k0; k < k1; k += 4) {
-      V3 p[4];
-      int id[4];
+    const int2 kr = o.range[prev];
+    for (int k = kr.x; k < kr.y; k += 4) {
+      double4 p[4];
 #pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const int kk = k + q < k1 ? k + q : k1 - 1;
-        p[q] = ld3(o.nbr + 3 * (size_t)kk);
-        id[q] = o.adj[kk];
-      }
+      for (int q = 0; q < 4; q++) p[q] = o.nbr4[k + q < kr.y ? k + q : kr.y - 1];
 #pragma unroll
       for (int q = 0; q < 4; q++) {
         const double val = p[q].x * d.x + p[q].y * d.y + p[q].z * d.z;
-        if (val > vmax) { vmax = val; imax = id[q]; best = p[q]; }
+        if (val > vmax) { vmax = val; imax = __double2loint(p[q].w); best = {p[q].x, p[q].y, p[q].z}; }
       }
     }
   }
@@ -192,97 +193,114 @@ __device__ inline double origin_tri_dist2(const V3& a, const V3& b, const V3& c,
   return dot(w, w);
 }
 
-// returns true when the inflated hulls intersect; fills depth, dir (unit, obj1 -> obj2), pos
+// returns true when the inflated hulls intersect; fills depth, dir (unit, obj1 -> obj2), pos.
+// Same arithmetic as the textbook phase-by-phase MPR (discover portal, refine until the portal
+// encloses the origin ray, push the portal to the surface); written as one loop around a single
+// support call so that the lanes of a wavefront, which sit in different phases, stay converged
+// on the expensive part.
 __device__ inline bool mpr_penetration(CObj& a, CObj& b, double tol, int maxit, double& depth, V3& dir, V3& pos,
                                        int& iters) {
   Spt P[4];
   const V3 origin = {0, 0, 0};
   P[0].v1 = a.xpos; P[0].v2 = b.xpos; P[0].v = sub(P[0].v1, P[0].v2);
   if (v_eq(P[0].v, origin)) P[0].v = {BS_CCD_EPS * 10, 0, 0};
+  P[1] = P[0]; P[2] = P[0]; P[3] = P[0];
   V3 d = normalized(neg(P[0].v));
-  P[1] = md_support(a, b, d);
-  double dt = dot(P[1].v, d);
-  if (c_is_zero(dt) || dt < 0) return false;
-  d = cross(P[0].v, P[1].v);
-  if (c_is_zero(dot(d, d))) {
-    pos = {0.5 * (P[1].v1.x + P[1].v2.x), 0.5 * (P[1].v1.y + P[1].v2.y), 0.5 * (P[1].v1.z + P[1].v2.z)};
-    if (v_eq(P[1].v, origin)) { depth = 0; dir = origin; return true; }  // touching
-    depth = sqrt(dot(P[1].v, P[1].v));
-    dir = normalized(P[1].v);
-    return true;  // origin on the segment v0-v1
-  }
-  d = normalized(d);
-  P[2] = md_support(a, b, d);
-  dt = dot(P[2].v, d);
-  if (c_is_zero(dt) || dt < 0) return false;
-  d = normalized(cross(sub(P[1].v, P[0].v), sub(P[2].v, P[0].v)));
-  if (dot(d, P[0].v) > 0) {
-    const Spt t = P[1]; P[1] = P[2]; P[2] = t;
-    d = neg(d);
-  }
-  int guard = 0;
+  int state = 0, guard = 0, it = 0;
   for (;;) {
-    if (++guard > 100) return false;
-    P[3] = md_support(a, b, d);
-    dt = dot(P[3].v, d);
-    if (c_is_zero(dt) || dt < 0) return false;
-    bool cont = false;
-    double x = dot(cross(P[1].v, P[3].v), P[0].v);
-    if (x < 0 && !c_is_zero(x)) { P[2] = P[3]; cont = true; }
-    if (!cont) {
-      x = dot(cross(P[3].v, P[2].v), P[0].v);
-      if (x < 0 && !c_is_zero(x)) { P[1] = P[3]; cont = true; }
-    }
-    if (!cont) break;
-    d = normalized(cross(sub(P[1].v, P[0].v), sub(P[2].v, P[0].v)));
-  }
-  // refine the portal until it encloses the origin
-  bool inside = false;
-  for (int it = 0; it <= maxit + 1; it++) {
-    d = portal_dir(P);
-    const double x = dot(d, P[1].v);
-    if (c_is_zero(x) || x > 0) { inside = true; break; }
-    const Spt v4 = md_support(a, b, d);
-    iters++;
-    const double y = dot(v4.v, d);
-    if (!(c_is_zero(y) || y > 0) || reach_tol(P, v4, d, tol)) return false;
-    expand_portal(P, v4);
-  }
-  if (!inside) return false;
-  // penetration: push the portal to the surface
-  for (int it = 0;; it++) {
-    d = portal_dir(P);
-    const Spt v4 = md_support(a, b, d);
-    iters++;
-    if (reach_tol(P, v4, d, tol) || it > maxit) {
-      V3 w;
-      depth = sqrt(origin_tri_dist2(P[1].v, P[2].v, P[3].v, w));
-      dir = c_is_zero(depth) ? origin : normalized(w);
-      // position from barycentric coordinates of the origin in the portal tetrahedron
-      double bb[4];
-      bb[0] = dot(cross(P[1].v, P[2].v), P[3].v);
-      bb[1] = dot(cross(P[3].v, P[2].v), P[0].v);
-      bb[2] = dot(cross(P[0].v, P[1].v), P[3].v);
-      bb[3] = dot(cross(P[2].v, P[1].v), P[0].v);
-      double sum = bb[0] + bb[1] + bb[2] + bb[3];
-      if (c_is_zero(sum) || sum < 0) {
-        bb[0] = 0;
-        bb[1] = dot(cross(P[2].v, P[3].v), d);
-        bb[2] = dot(cross(P[3].v, P[1].v), d);
-        bb[3] = dot(cross(P[1].v, P[2].v), d);
-        sum = bb[1] + bb[2] + bb[3];
+    const Spt s = md_support(a, b, d);
+    bool check_refine = false;
+    if (state == 0) {
+      P[1] = s;
+      const double dt = dot(P[1].v, d);
+      if (c_is_zero(dt) || dt < 0) return false;
+      d = cross(P[0].v, P[1].v);
+      if (c_is_zero(dot(d, d))) {
+        pos = {0.5 * (P[1].v1.x + P[1].v2.x), 0.5 * (P[1].v1.y + P[1].v2.y), 0.5 * (P[1].v1.z + P[1].v2.z)};
+        if (v_eq(P[1].v, origin)) { depth = 0; dir = origin; return true; }  // touching
+        depth = sqrt(dot(P[1].v, P[1].v));
+        dir = normalized(P[1].v);
+        return true;  // origin on the segment v0-v1
       }
-      const double inv = 1.0 / sum;
-      V3 p1 = {0, 0, 0}, p2 = {0, 0, 0};
+      d = normalized(d);
+      state = 1;
+    } else if (state == 1) {
+      P[2] = s;
+      const double dt = dot(P[2].v, d);
+      if (c_is_zero(dt) || dt < 0) return false;
+      d = normalized(cross(sub(P[1].v, P[0].v), sub(P[2].v, P[0].v)));
+      if (dot(d, P[0].v) > 0) {
+        const Spt t = P[1]; P[1] = P[2]; P[2] = t;
+        d = neg(d);
+      }
+      guard = 1;
+      state = 2;
+    } else if (state == 2) {  // portal discovery
+      P[3] = s;
+      const double dt = dot(P[3].v, d);
+      if (c_is_zero(dt) || dt < 0) return false;
+      bool cont = false;
+      double x = dot(cross(P[1].v, P[3].v), P[0].v);
+      if (x < 0 && !c_is_zero(x)) { P[2] = P[3]; cont = true; }
+      if (!cont) {
+        x = dot(cross(P[3].v, P[2].v), P[0].v);
+        if (x < 0 && !c_is_zero(x)) { P[1] = P[3]; cont = true; }
+      }
+      if (cont) {
+        d = normalized(cross(sub(P[1].v, P[0].v), sub(P[2].v, P[0].v)));
+        if (++guard > 100) return false;
+      } else {
+        it = 0;
+        check_refine = true;
+      }
+    } else if (state == 3) {  // refinement
+      iters++;
+      const double y = dot(s.v, d);
+      if (!(c_is_zero(y) || y > 0) || reach_tol(P, s, d, tol)) return false;
+      expand_portal(P, s);
+      it++;
+      check_refine = true;
+    } else {  // penetration: push the portal to the surface
+      iters++;
+      if (reach_tol(P, s, d, tol) || it > maxit) {
+        V3 w;
+        depth = sqrt(origin_tri_dist2(P[1].v, P[2].v, P[3].v, w));
+        dir = c_is_zero(depth) ? origin : normalized(w);
+        // position from barycentric coordinates of the origin in the portal tetrahedron
+        double bb[4];
+        bb[0] = dot(cross(P[1].v, P[2].v), P[3].v);
+        bb[1] = dot(cross(P[3].v, P[2].v), P[0].v);
+        bb[2] = dot(cross(P[0].v, P[1].v), P[3].v);
+        bb[3] = dot(cross(P[2].v, P[1].v), P[0].v);
+        double sum = bb[0] + bb[1] + bb[2] + bb[3];
+        if (c_is_zero(sum) || sum < 0) {
+          bb[0] = 0;
+          bb[1] = dot(cross(P[2].v, P[3].v), d);
+          bb[2] = dot(cross(P[3].v, P[1].v), d);
+          bb[3] = dot(cross(P[1].v, P[2].v), d);
+          sum = bb[1] + bb[2] + bb[3];
+        }
+        const double inv = 1.0 / sum;
+        V3 p1 = {0, 0, 0}, p2 = {0, 0, 0};
 #pragma unroll
-      for (int i = 0; i < 4; i++) {
-        p1.x += bb[i] * P[i].v1.x; p1.y += bb[i] * P[i].v1.y; p1.z += bb[i] * P[i].v1.z;
-        p2.x += bb[i] * P[i].v2.x; p2.y += bb[i] * P[i].v2.y; p2.z += bb[i] * P[i].v2.z;
+        for (int i = 0; i < 4; i++) {
+          p1.x += bb[i] * P[i].v1.x; p1.y += bb[i] * P[i].v1.y; p1.z += bb[i] * P[i].v1.z;
+          p2.x += bb[i] * P[i].v2.x; p2.y += bb[i] * P[i].v2.y; p2.z += bb[i] * P[i].v2.z;
+        }
+        pos = {0.5 * (p1.x * inv + p2.x * inv), 0.5 * (p1.y * inv + p2.y * inv), 0.5 * (p1.z * inv + p2.z * inv)};
+        return true;
       }
-      pos = {0.5 * (p1.x * inv + p2.x * inv), 0.5 * (p1.y * inv + p2.y * inv), 0.5 * (p1.z * inv + p2.z * inv)};
-      return true;
+      expand_portal(P, s);
+      it++;
+      d = portal_dir(P);
     }
-    expand_portal(P, v4);
+    if (check_refine) {
+      if (it > maxit + 1) return false;
+      d = portal_dir(P);
+      const double x = dot(d, P[1].v);
+      if (c_is_zero(x) || x > 0) { it = 0; state = 4; }  // portal encloses the origin ray
+      else state = 3;
+    }
   }
 }
 
@@ -396,9 +414,9 @@ __device__ inline void col_narrowphase(const ColModel& cm, const DevData& d, con
   CObj b;
   {
     const int mesh = cm.geom_dataid[g2];
-    b.vertadr = cm.mesh_vertadr[mesh];
-    b.vert = cm.hull_vert + 3 * (size_t)b.vertadr;
-    b.adj_start = cm.hull_adj_start; b.adj = cm.hull_adj; b.cache = 0; b.nbr = cm.hull_nbr;
+    b.vert4 = cm.hull_vert4 + cm.mesh_vertadr[mesh];
+    b.range = cm.hull_range + cm.mesh_vertadr[mesh];
+    b.nbr4 = cm.hull_nbr4; b.cache = 0;
     b.start = cm.hull_start + (size_t)mesh * BS_NSTART;
     b.xpos = {AT(c.geom_xpos, 3 * g2), AT(c.geom_xpos, 3 * g2 + 1), AT(c.geom_xpos, 3 * g2 + 2)};
     for (int k = 0; k < 9; k++) b.R.a[k] = AT(c.geom_xmat, 9 * g2 + k);
@@ -419,9 +437,9 @@ __device__ inline void col_narrowphase(const ColModel& cm, const DevData& d, con
   } else {
     CObj a;
     const int mesh = cm.geom_dataid[g1];
-    a.vertadr = cm.mesh_vertadr[mesh];
-    a.vert = cm.hull_vert + 3 * (size_t)a.vertadr;
-    a.adj_start = cm.hull_adj_start; a.adj = cm.hull_adj; a.cache = 0; a.nbr = cm.hull_nbr;
+    a.vert4 = cm.hull_vert4 + cm.mesh_vertadr[mesh];
+    a.range = cm.hull_range + cm.mesh_vertadr[mesh];
+    a.nbr4 = cm.hull_nbr4; a.cache = 0;
     a.start = cm.hull_start + (size_t)mesh * BS_NSTART;
     a.xpos = {AT(c.geom_xpos, 3 * g1), AT(c.geom_xpos, 3 * g1 + 1), AT(c.geom_xpos, 3 * g1 + 2)};
     for (int k = 0; k < 9; k++) a.R.a[k] = AT(c.geom_xmat, 9 * g1 + k);
