@@ -579,7 +579,15 @@ __global__ __launch_bounds__(64, 2) void k_tp(DevModel m, TpModel t, DevData d, 
   const TpShared sh = {tbl, nullptr, nullptr, nullptr};
   ColModel cm;
   ColData cd;
-  tp_run<false>(m, t, d, nsteps, mode, dump, sh, cm, cd);
+  tp_run<false, false>(m, t, d, nsteps, mode, dump, sh, cm, cd);
+}
+// same, with every intermediate the parity tests read written out (bs_forward)
+__global__ __launch_bounds__(64, 2) void k_tp_full(DevModel m, TpModel t, DevData d, int nsteps, int mode, int dump) {
+  __shared__ int tbl[TPL_TOTAL * 64];
+  const TpShared sh = {tbl, nullptr, nullptr, nullptr};
+  ColModel cm;
+  ColData cd;
+  tp_run<false, true>(m, t, d, nsteps, mode, dump, sh, cm, cd);
 }
 // kinematics + geom frames + broadphase, tree-parallel layout (physics_tp.h::tp_collide_prep)
 __global__ __launch_bounds__(64) void k_tp_col(DevModel m, TpModel t, DevData d, ColModel cm, ColData cd) {
@@ -597,7 +605,7 @@ __global__ __launch_bounds__(64, TPC_OCC) void k_tpc(DevModel m, TpModel t, DevD
   extern __shared__ double tpc_dyn[];
   const int ntri = m.nbody * (m.nbody + 1) / 2;
   const TpShared sh = {tbl, tpc_dyn, tpc_dyn + 2 * ntri, tpc_dyn + 2 * ntri + 2 * TP_LPE * TPC_SLOT};
-  tp_run<true>(m, t, d, 1, mode, dump, sh, cm, cd);
+  tp_run<true, false>(m, t, d, 1, mode, dump, sh, cm, cd);
 }
 __global__ __launch_bounds__(BS_BLOCK) void k_forward(DevModel m, DevData d) {
   const long e = (long)blockIdx.x * BS_BLOCK + threadIdx.x;
@@ -955,7 +963,7 @@ extern "C" int bs_forward(bs_sim* s) {
   if (s->contacts)
     launch_contact_pass(s, 0, 0);
   else if (s->use_tp)
-    hipLaunchKernelGGL(k_tp, grid_tp(s), dim3(64), 0, s->stream, s->dm, s->tp, s->dd, 1, 1, 2);
+    hipLaunchKernelGGL(k_tp_full, grid_tp(s), dim3(64), 0, s->stream, s->dm, s->tp, s->dd, 1, 1, 2);
   else
     hipLaunchKernelGGL(k_forward, grid_for(s), dim3(BS_BLOCK), 0, s->stream, s->dm, s->dd);
   HIPCHK(hipGetLastError());

@@ -551,7 +551,7 @@ __device__ __forceinline__ void tp_collide_prep(const DevModel& m, const TpModel
 // generalized forces of the last forward pass, 2: every intermediate the parity tests read.
 // CON: one step per launch with the contact candidates of k_c_broad / k_c_narrow (physics_collide.h):
 // contact assembly, pyramid rows owned by lanes, dense Hessian per environment in LDS.
-template <bool CON>
+template <bool CON, bool FULL>
 __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, const DevData& d, int nsteps,
                                        int mode, int dump, TpShared sh, const ColModel& cm, const ColData& cd) {
   int* tbl = sh.tbl;
@@ -1329,7 +1329,7 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
           AT(d.qacc_smooth, j) = qacc_smooth; AT(d.qfrc_constraint, j) = qfrc_constraint;
         }
         if (act >= 0) AT(d.actuator_force, act) = act_force;
-        if (dump >= 2) {
+        if (FULL && dump >= 2) {
           if (l < m.nbody) {
             AT(d.xipos, 3 * b) = xipos.x; AT(d.xipos, 3 * b + 1) = xipos.y; AT(d.xipos, 3 * b + 2) = xipos.z;
             if (root == b && b > 0) {
