@@ -61,6 +61,8 @@ def _pool_worker(args):
     model = Model.load(path)
     if not contacts:
         model = workload.contact_free(model)
+    else:
+        model = workload.with_ground_plane(model, z=-0.05)
     q, v = workload.config2_state(model, n_envs, seed=seed)
     c = workload.config2_ctrl(model, n_envs, seed=seed)
     t0 = time.perf_counter()
@@ -120,8 +122,8 @@ def main():
     model = Model.load(model_path)
     if not args.contacts:
         model = workload.contact_free(model)
-    global cpu_model_contacts
-    cpu_model_contacts = args.contacts  # noqa: F841 (informational)
+    else:
+        model = workload.with_ground_plane(model, z=-0.05)
     E = args.envs
     seed = 1234 + 1000 * rank
     q, v = workload.config2_state(model, E, seed=seed)
@@ -223,10 +225,11 @@ def main():
             "stage_ms_one_step": stage,
         }
         if cstat:
-            out["config"]["workload"] = ("BASELINE.json configs[2] shape: DexterousDynamos.xml with STL-hull mesh "
-                                         "self-collision (no ground plane: the hand cannot reach one), Euler + Newton")
+            out["config"]["workload"] = ("BASELINE.json configs[2]: DexterousDynamos.xml with STL-hull mesh "
+                                         "self-collision + a ground plane at z=-0.05 (the plane is this build's "
+                                         "augmentation, not in the reference XML), Euler + Newton, fp64")
             out["config"]["collision"] = cstat
-            out["roofline"]["kernel"] = "k_c_pos+k_c_broad+k_c_narrow+k_c_dyn (one step = 4 launches)"
+            out["roofline"]["kernel"] = "k_tp_col+k_c_narrow_flat+k_tpc (one step = 3 launches)"
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(model)
             try:

@@ -169,6 +169,9 @@ static void build_tp(bs_model* m) {
 }
 
 namespace {
+inline int64_t pack_rec(int id, int deg, int k0) {
+  return (int64_t)(((uint64_t)(uint32_t)k0 << 32) | ((uint64_t)(deg & 0xFFF) << 20) | (uint64_t)(id & 0xFFFFF));
+}
 struct Packer {
   std::vector<char> bytes;
   size_t add(const void* p, size_t n) {
@@ -237,6 +240,8 @@ extern "C" int bs_model_create(const bs_model_desc* desc, bs_model** out) {
       if (desc->hull_adj_start[v] < 0 || desc->hull_adj_start[v + 1] < desc->hull_adj_start[v] ||
           desc->hull_adj_start[v + 1] > desc->nhulladj)
         return fail(BS_ERR_INVALID, "hull vertex %d: bad adjacency range", v);
+      if (desc->hull_adj_start[v + 1] - desc->hull_adj_start[v] > 0xFFF || desc->mesh_vertnum[me] > 0xFFFFF)
+        return fail(BS_ERR_UNSUPPORTED, "bs_model_create: hull %d exceeds 2^20 vertices or a vertex has more than 4095 neighbours", me);
       for (int q = desc->hull_adj_start[v]; q < desc->hull_adj_start[v + 1]; q++)
         if (desc->hull_adj[q] < 0 || desc->hull_adj[q] >= desc->mesh_vertnum[me])
           return fail(BS_ERR_INVALID, "hull vertex %d: neighbour out of range", v);
@@ -479,6 +484,16 @@ static int model_image(bs_model* m, int device, const DeviceImage** out) {
     }
   }
   PUT_CI(hull_start, hstart.data(), hstart.size());
+  std::vector<double> start4(hstart.size() * 4, 0.0);
+  for (int me = 0; me < s.nmesh; me++)
+    for (int bin = 0; bin < BS_NSTART; bin++) {
+      const int va = s.mesh_vertadr[me], v = hstart[(size_t)me * BS_NSTART + bin];
+      double* r = &start4[4 * ((size_t)me * BS_NSTART + bin)];
+      for (int q = 0; q < 3; q++) r[q] = s.hull_vert[3 * ((size_t)va + v) + q];
+      const int64_t bits = pack_rec(v, s.hull_adj_start[va + v + 1] - s.hull_adj_start[va + v], s.hull_adj_start[va + v]);
+      memcpy(r + 3, &bits, sizeof bits);
+    }
+  fix.push_back({pk.add(start4.data(), start4.size() * sizeof(double)), (void**)&cm.hull_start4});
   // hill-climbing records: neighbour {x, y, z, id} per adjacency entry, padded vertices, ranges
   std::vector<double> nbr4((size_t)(s.nhulladj > 0 ? s.nhulladj : 1) * 4, 0.0);
   std::vector<double> vert4((size_t)(s.nhullvert > 0 ? s.nhullvert : 1) * 4, 0.0);
@@ -491,7 +506,8 @@ static int model_image(bs_model* m, int device, const DeviceImage** out) {
       range[2 * ((size_t)va + v) + 1] = s.hull_adj_start[va + v + 1];
       for (int k = s.hull_adj_start[va + v]; k < s.hull_adj_start[va + v + 1]; k++) {
         for (int q = 0; q < 3; q++) nbr4[4 * (size_t)k + q] = s.hull_vert[3 * ((size_t)va + s.hull_adj[k]) + q];
-        const int64_t bits = (int64_t)(uint32_t)s.hull_adj[k];  // id in the low word of the 4th double
+        const int nb = s.hull_adj[k];  // named vertex: id | degree << 20 | first adjacency entry << 32
+        const int64_t bits = pack_rec(nb, s.hull_adj_start[va + nb + 1] - s.hull_adj_start[va + nb], s.hull_adj_start[va + nb]);
         memcpy(&nbr4[4 * (size_t)k + 3], &bits, sizeof bits);
       }
     }
@@ -545,6 +561,7 @@ struct bs_sim {
   DevModel dm;
   TpModel tp;
   bool use_tp = false;
+  bool narrow_ws = false;
   bool use_tpc = false;  // contacts: tree-parallel dynamics kernel instead of the serial k_c_dyn (steps only)
   bool contacts = false;
   ColModel cm;
@@ -594,7 +611,7 @@ __global__ __launch_bounds__(64) void k_tp_col(DevModel m, TpModel t, DevData d,
   extern __shared__ double tpg_dyn[];  // geom frames of the two environments
   tp_collide_prep(m, t, d, cm, cd, tpg_dyn);
 }
-// tree-parallel step with contacts: candidates from k_c_broad / k_c_narrow, one step per launch
+// tree-parallel step with contacts: candidates from k_tp_col + the narrowphase kernel, one step per launch
 #ifndef TPC_OCC
 #define TPC_OCC 2
 #endif
@@ -685,11 +702,6 @@ __global__ __launch_bounds__(64) void k_c_broad(ColModel cm, DevData d, ColData 
   if (e >= d.n_envs) return;
   col_broadphase(cm, d, c, e, threadIdx.x);
 }
-__global__ __launch_bounds__(BS_BLOCK) void k_c_narrow(ColModel cm, DevData d, ColData c) {
-  const long e = (long)blockIdx.x * BS_BLOCK + threadIdx.x;
-  if (e >= d.n_envs) return;
-  col_narrowphase(cm, d, c, e, blockIdx.y);
-}
 // narrowphase over the flattened (environment, candidate slot) items of NB_ENVS environments:
 // an exclusive scan of the candidate counts in LDS, then every lane takes items round-robin, so
 // no lane idles on environments with few candidates and no wavefront is launched for empty slots
@@ -711,6 +723,7 @@ __global__ __launch_bounds__(NB_THREADS) void k_c_narrow_flat(ColModel cm, DevDa
   }
   __syncthreads();
   const int total = pre[NB_ENVS];
+  unsigned acc[2] = {0, 0};
   for (int item = tid; item < total; item += NB_THREADS) {
     int lo = 0, hi = NB_ENVS;  // largest env index with pre[env] <= item
     while (hi - lo > 1) {
@@ -718,7 +731,47 @@ __global__ __launch_bounds__(NB_THREADS) void k_c_narrow_flat(ColModel cm, DevDa
       if (pre[mid] <= item) lo = mid;
       else hi = mid;
     }
-    col_narrowphase(cm, d, c, e0 + lo, item - pre[lo]);
+    col_narrowphase(cm, d, c, e0 + lo, item - pre[lo], acc);
+  }
+  if (c.stat) {  // work counters: wavefront reduction, then one atomic each
+    for (int off = 32; off > 0; off >>= 1) {
+      acc[0] += __shfl_down(acc[0], off, 64);
+      acc[1] += __shfl_down(acc[1], off, 64);
+    }
+    if ((tid & 63) == 0 && acc[0]) {
+      atomicAdd(c.stat, (unsigned long long)acc[0]);
+      atomicAdd(c.stat + 1, (unsigned long long)acc[1]);
+    }
+  }
+}
+#define NW_THREADS 128
+__global__ __launch_bounds__(NW_THREADS) void k_c_narrow_ws(ColModel cm, DevData d, ColData c) {
+  __shared__ int pre[NB_ENVS + 1];
+  __shared__ int next;
+  const long e0 = (long)blockIdx.x * NB_ENVS;
+  const int tid = threadIdx.x;
+  if (tid < NB_ENVS) {
+    const long e = e0 + tid, E = d.E;
+    int v = e < d.n_envs ? AT(c.ncand, 0) : 0;
+    for (int off = 1; off < NB_ENVS; off <<= 1) {
+      const int u = __shfl_up(v, off, 64);
+      if (tid >= off) v += u;
+    }
+    pre[tid + 1] = v;
+    if (tid == 0) { pre[0] = 0; next = 0; }
+  }
+  __syncthreads();
+  unsigned acc[2] = {0, 0};
+  col_narrow_ws(cm, d, c, e0, pre, NB_ENVS, &next, acc);
+  if (c.stat) {
+    for (int off = 32; off > 0; off >>= 1) {
+      acc[0] += __shfl_down(acc[0], off, 64);
+      acc[1] += __shfl_down(acc[1], off, 64);
+    }
+    if ((tid & 63) == 0 && acc[0]) {
+      atomicAdd(c.stat, (unsigned long long)acc[0]);
+      atomicAdd(c.stat + 1, (unsigned long long)acc[1]);
+    }
   }
 }
 __global__ __launch_bounds__(BS_BLOCK) void k_c_dyn(DevModel m, ColModel cm, DevData d, ColData c, ConData k,
@@ -737,6 +790,15 @@ __global__ __launch_bounds__(BS_BLOCK) void k_c_dyn(DevModel m, ColModel cm, Dev
 
 static inline dim3 grid_for(const bs_sim* s) { return dim3((unsigned)((s->n_envs + BS_BLOCK - 1) / BS_BLOCK)); }
 static inline dim3 grid_tp(const bs_sim* s) { return dim3((unsigned)((s->n_envs + 1) / 2)); }
+// narrowphase: flattened work items by default; BS_NARROW=ws selects the work-stealing variant
+// (measured slower on MI355X at 65536 envs: 2.6 ms vs 1.9 ms)
+static void launch_narrow(bs_sim* s) {
+  const dim3 g((unsigned)((s->n_envs + NB_ENVS - 1) / NB_ENVS));
+  if (s->narrow_ws)
+    hipLaunchKernelGGL(k_c_narrow_ws, g, dim3(NW_THREADS), 0, s->stream, s->cm, s->dd, s->cd);
+  else
+    hipLaunchKernelGGL(k_c_narrow_flat, g, dim3(NB_THREADS), 0, s->stream, s->cm, s->dd, s->cd);
+}
 static void launch_contact_pass(bs_sim* s, int check, int integrate, int dump = 1) {
   const dim3 g = dim3((unsigned)((s->n_envs + BS_BLOCK - 1) / BS_BLOCK));
   if (s->use_tpc && integrate) {
@@ -746,11 +808,7 @@ static void launch_contact_pass(bs_sim* s, int check, int integrate, int dump = 
     hipLaunchKernelGGL(k_c_pos, g, dim3(BS_BLOCK), 0, s->stream, s->dm, s->dd, s->cd, check);
     hipLaunchKernelGGL(k_c_broad, dim3((unsigned)s->n_envs), dim3(64), 0, s->stream, s->cm, s->dd, s->cd);
   }
-  if (getenv("BS_NARROW_GRID"))
-    hipLaunchKernelGGL(k_c_narrow, dim3(g.x, (unsigned)s->cm.maxcand), dim3(BS_BLOCK), 0, s->stream, s->cm, s->dd, s->cd);
-  else
-    hipLaunchKernelGGL(k_c_narrow_flat, dim3((unsigned)((s->n_envs + NB_ENVS - 1) / NB_ENVS)), dim3(NB_THREADS), 0, s->stream,
-                       s->cm, s->dd, s->cd);
+  launch_narrow(s);
   if (s->use_tpc && integrate) {
     const int ntri = s->dm.nbody * (s->dm.nbody + 1) / 2;
     const size_t lds = (size_t)(2 * ntri + 2 * TP_LPE * TPC_SLOT + 2 * TP_LPE * 3) * sizeof(double);
@@ -808,6 +866,10 @@ extern "C" int bs_sim_create(const bs_model* const* models, int n_models, const 
   s->use_tp = !contacts && model->d.solver == 2 && model->tp_ok && !(kv && strcmp(kv, "serial") == 0);
   s->use_tpc = contacts && model->d.solver == 2 && model->tp_ok && s->cm.maxcon <= TP_LPE &&
                !(kv && strcmp(kv, "serial") == 0);
+  {
+    const char* nk = getenv("BS_NARROW");
+    s->narrow_ws = nk && strcmp(nk, "ws") == 0;
+  }
   if (kv && strcmp(kv, "tp") == 0 && !model->tp_ok) {
     delete s;
     return fail(BS_ERR_UNSUPPORTED, "BS_KERNEL=tp but the model is not eligible: %s", model->tp_why.c_str());
@@ -1100,7 +1162,7 @@ extern "C" int bs_stage_times(bs_sim* s, double* ms, int n) {
     hipLaunchKernelGGL(k_c_pos, g, dim3(BS_BLOCK), 0, s->stream, s->dm, s->dd, s->cd, 1);
     HIPCHK(hipEventRecord(s->ev[1], s->stream));
     hipLaunchKernelGGL(k_c_broad, dim3((unsigned)s->n_envs), dim3(64), 0, s->stream, s->cm, s->dd, s->cd);
-    hipLaunchKernelGGL(k_c_narrow, dim3(g.x, (unsigned)s->cm.maxcand), dim3(BS_BLOCK), 0, s->stream, s->cm, s->dd, s->cd);
+    launch_narrow(s);
     HIPCHK(hipEventRecord(s->ev[2], s->stream));
     hipLaunchKernelGGL(k_c_dyn, g, dim3(BS_BLOCK), s->hs_bytes, s->stream, s->dm, s->cm, s->dd, s->cd, s->kd, 1,
                        s->hs_bytes ? 1 : 0);

@@ -28,7 +28,9 @@ struct ColModel {
   // hill-climbing data packed for few, wide loads (divergent 8-byte loads are what bounds the
   // narrowphase): per adjacency entry {x, y, z, vertex id} of the neighbour, per vertex
   // {x, y, z, -} and its adjacency range {first, end}
+  // record.w packs the named vertex: id (bits 0-19), degree (20-31), first adjacency entry (32-63)
   const double4 *hull_nbr4;  // [nhulladj]
+  const double4 *hull_start4; // [nmesh][BS_NSTART] record of hull_start's vertex (work-stealing narrowphase)
   const double4 *hull_vert4; // [nhullvert]
   const int2 *hull_range;    // [nhullvert]
   const double *geom_obb; // [ngeom][6] box around the hull in the geom frame: centre, half extents (< 0: none)
@@ -80,6 +82,7 @@ __device__ __forceinline__ bool c_is_eq(double a, double b) {
 }
 __device__ __forceinline__ double dot(const V3& a, const V3& b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 __device__ __forceinline__ V3 sub(const V3& a, const V3& b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ V3 sub3(const V3& a, const V3& b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
 __device__ __forceinline__ V3 neg(const V3& a) { return {-a.x, -a.y, -a.z}; }
 __device__ __forceinline__ V3 normalized(const V3& a) {
   const double n = sqrt(dot(a, a));
@@ -89,6 +92,10 @@ __device__ __forceinline__ V3 normalized(const V3& a) {
 __device__ __forceinline__ bool v_eq(const V3& a, const V3& b) {
   return c_is_eq(a.x, b.x) && c_is_eq(a.y, b.y) && c_is_eq(a.z, b.z);
 }
+
+__device__ __forceinline__ int rec_id(double w) { return __double2loint(w) & 0xFFFFF; }
+__device__ __forceinline__ int rec_deg(double w) { return (__double2loint(w) >> 20) & 0xFFF; }
+__device__ __forceinline__ int rec_k0(double w) { return __double2hiint(w); }
 
 struct CObj {
   const double4 *vert4, *nbr4;  // vert4: this mesh's vertices; nbr4: global adjacency records
@@ -127,7 +134,7 @@ __device__ inline V3 hull_support(CObj& o, const V3& dir) {
 #pragma unroll
       for (int q = 0; q < 4; q++) {
         const double val = p[q].x * d.x + p[q].y * d.y + p[q].z * d.z;
-        if (val > vmax) { vmax = val; imax = __double2loint(p[q].w); best = {p[q].x, p[q].y, p[q].z}; }
+        if (val > vmax) { vmax = val; imax = rec_id(p[q].w); best = {p[q].x, p[q].y, p[q].z}; }
       }
     }
   }
@@ -193,114 +200,137 @@ __device__ inline double origin_tri_dist2(const V3& a, const V3& b, const V3& c,
   return dot(w, w);
 }
 
-// returns true when the inflated hulls intersect; fills depth, dir (unit, obj1 -> obj2), pos.
-// Same arithmetic as the textbook phase-by-phase MPR (discover portal, refine until the portal
-// encloses the origin ray, push the portal to the surface); written as one loop around a single
-// support call so that the lanes of a wavefront, which sit in different phases, stay converged
-// on the expensive part.
+// Minkowski Portal Refinement, one transition per support point.  The textbook phases (discover
+// portal, refine until the portal encloses the origin ray, push the portal to the surface) are the
+// values of `state`; the caller owns the loop around the support call, so the lanes of a
+// wavefront stay converged on the expensive part whatever phase each one is in.
+struct MprState {
+  Spt P[4];
+  V3 d;           // direction of the next support query
+  int state, guard, it;
+};
+__device__ __forceinline__ void mpr_begin(MprState& M, const V3& c1, const V3& c2) {
+  const V3 origin = {0, 0, 0};
+  M.P[0].v1 = c1; M.P[0].v2 = c2; M.P[0].v = sub(c1, c2);
+  if (v_eq(M.P[0].v, origin)) M.P[0].v = {BS_CCD_EPS * 10, 0, 0};
+  M.P[1] = M.P[0]; M.P[2] = M.P[0]; M.P[3] = M.P[0];
+  M.d = normalized(neg(M.P[0].v));
+  M.state = 0; M.guard = 0; M.it = 0;
+}
+// consumes the support point `s` of direction M.d; returns 0 = query M.d again, 1 = the inflated
+// hulls intersect (depth, dir = unit normal obj1 -> obj2, pos filled), 2 = they do not
+__device__ __forceinline__ int mpr_step(MprState& M, const Spt& s, double tol, int maxit, double& depth, V3& dir,
+                                        V3& pos, int& iters) {
+  Spt* P = M.P;
+  V3& d = M.d;
+  int& state = M.state;
+  int& guard = M.guard;
+  int& it = M.it;
+  const V3 origin = {0, 0, 0};
+  bool check_refine = false;
+  if (state == 0) {
+    P[1] = s;
+    const double dt = dot(P[1].v, d);
+    if (c_is_zero(dt) || dt < 0) return 2;
+    d = cross(P[0].v, P[1].v);
+    if (c_is_zero(dot(d, d))) {
+      pos = {0.5 * (P[1].v1.x + P[1].v2.x), 0.5 * (P[1].v1.y + P[1].v2.y), 0.5 * (P[1].v1.z + P[1].v2.z)};
+      if (v_eq(P[1].v, origin)) { depth = 0; dir = origin; return 1; }  // touching
+      depth = sqrt(dot(P[1].v, P[1].v));
+      dir = normalized(P[1].v);
+      return 1;  // origin on the segment v0-v1
+    }
+    d = normalized(d);
+    state = 1;
+  } else if (state == 1) {
+    P[2] = s;
+    const double dt = dot(P[2].v, d);
+    if (c_is_zero(dt) || dt < 0) return 2;
+    d = normalized(cross(sub(P[1].v, P[0].v), sub(P[2].v, P[0].v)));
+    if (dot(d, P[0].v) > 0) {
+      const Spt t = P[1]; P[1] = P[2]; P[2] = t;
+      d = neg(d);
+    }
+    guard = 1;
+    state = 2;
+  } else if (state == 2) {  // portal discovery
+    P[3] = s;
+    const double dt = dot(P[3].v, d);
+    if (c_is_zero(dt) || dt < 0) return 2;
+    bool cont = false;
+    double x = dot(cross(P[1].v, P[3].v), P[0].v);
+    if (x < 0 && !c_is_zero(x)) { P[2] = P[3]; cont = true; }
+    if (!cont) {
+      x = dot(cross(P[3].v, P[2].v), P[0].v);
+      if (x < 0 && !c_is_zero(x)) { P[1] = P[3]; cont = true; }
+    }
+    if (cont) {
+      d = normalized(cross(sub(P[1].v, P[0].v), sub(P[2].v, P[0].v)));
+      if (++guard > 100) return 2;
+    } else {
+      it = 0;
+      check_refine = true;
+    }
+  } else if (state == 3) {  // refinement
+    iters++;
+    const double y = dot(s.v, d);
+    if (!(c_is_zero(y) || y > 0) || reach_tol(P, s, d, tol)) return 2;
+    expand_portal(P, s);
+    it++;
+    check_refine = true;
+  } else {  // penetration: push the portal to the surface
+    iters++;
+    if (reach_tol(P, s, d, tol) || it > maxit) {
+      V3 w;
+      depth = sqrt(origin_tri_dist2(P[1].v, P[2].v, P[3].v, w));
+      dir = c_is_zero(depth) ? origin : normalized(w);
+      // position from barycentric coordinates of the origin in the portal tetrahedron
+      double bb[4];
+      bb[0] = dot(cross(P[1].v, P[2].v), P[3].v);
+      bb[1] = dot(cross(P[3].v, P[2].v), P[0].v);
+      bb[2] = dot(cross(P[0].v, P[1].v), P[3].v);
+      bb[3] = dot(cross(P[2].v, P[1].v), P[0].v);
+      double sum = bb[0] + bb[1] + bb[2] + bb[3];
+      if (c_is_zero(sum) || sum < 0) {
+        bb[0] = 0;
+        bb[1] = dot(cross(P[2].v, P[3].v), d);
+        bb[2] = dot(cross(P[3].v, P[1].v), d);
+        bb[3] = dot(cross(P[1].v, P[2].v), d);
+        sum = bb[1] + bb[2] + bb[3];
+      }
+      const double inv = 1.0 / sum;
+      V3 p1 = {0, 0, 0}, p2 = {0, 0, 0};
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        p1.x += bb[i] * P[i].v1.x; p1.y += bb[i] * P[i].v1.y; p1.z += bb[i] * P[i].v1.z;
+        p2.x += bb[i] * P[i].v2.x; p2.y += bb[i] * P[i].v2.y; p2.z += bb[i] * P[i].v2.z;
+      }
+      pos = {0.5 * (p1.x * inv + p2.x * inv), 0.5 * (p1.y * inv + p2.y * inv), 0.5 * (p1.z * inv + p2.z * inv)};
+      return 1;
+    }
+    expand_portal(P, s);
+    it++;
+    d = portal_dir(P);
+  }
+
+  if (check_refine) {
+    if (it > maxit + 1) return 2;
+    d = portal_dir(P);
+    const double x = dot(d, P[1].v);
+    if (c_is_zero(x) || x > 0) { it = 0; state = 4; }  // portal encloses the origin ray
+    else state = 3;
+  }
+  return 0;
+}
+// returns true when the inflated hulls intersect; fills depth, dir (unit, obj1 -> obj2), pos
 __device__ inline bool mpr_penetration(CObj& a, CObj& b, double tol, int maxit, double& depth, V3& dir, V3& pos,
                                        int& iters) {
-  Spt P[4];
-  const V3 origin = {0, 0, 0};
-  P[0].v1 = a.xpos; P[0].v2 = b.xpos; P[0].v = sub(P[0].v1, P[0].v2);
-  if (v_eq(P[0].v, origin)) P[0].v = {BS_CCD_EPS * 10, 0, 0};
-  P[1] = P[0]; P[2] = P[0]; P[3] = P[0];
-  V3 d = normalized(neg(P[0].v));
-  int state = 0, guard = 0, it = 0;
+  MprState M;
+  mpr_begin(M, a.xpos, b.xpos);
   for (;;) {
-    const Spt s = md_support(a, b, d);
-    bool check_refine = false;
-    if (state == 0) {
-      P[1] = s;
-      const double dt = dot(P[1].v, d);
-      if (c_is_zero(dt) || dt < 0) return false;
-      d = cross(P[0].v, P[1].v);
-      if (c_is_zero(dot(d, d))) {
-        pos = {0.5 * (P[1].v1.x + P[1].v2.x), 0.5 * (P[1].v1.y + P[1].v2.y), 0.5 * (P[1].v1.z + P[1].v2.z)};
-        if (v_eq(P[1].v, origin)) { depth = 0; dir = origin; return true; }  // touching
-        depth = sqrt(dot(P[1].v, P[1].v));
-        dir = normalized(P[1].v);
-        return true;  // origin on the segment v0-v1
-      }
-      d = normalized(d);
-      state = 1;
-    } else if (state == 1) {
-      P[2] = s;
-      const double dt = dot(P[2].v, d);
-      if (c_is_zero(dt) || dt < 0) return false;
-      d = normalized(cross(sub(P[1].v, P[0].v), sub(P[2].v, P[0].v)));
-      if (dot(d, P[0].v) > 0) {
-        const Spt t = P[1]; P[1] = P[2]; P[2] = t;
-        d = neg(d);
-      }
-      guard = 1;
-      state = 2;
-    } else if (state == 2) {  // portal discovery
-      P[3] = s;
-      const double dt = dot(P[3].v, d);
-      if (c_is_zero(dt) || dt < 0) return false;
-      bool cont = false;
-      double x = dot(cross(P[1].v, P[3].v), P[0].v);
-      if (x < 0 && !c_is_zero(x)) { P[2] = P[3]; cont = true; }
-      if (!cont) {
-        x = dot(cross(P[3].v, P[2].v), P[0].v);
-        if (x < 0 && !c_is_zero(x)) { P[1] = P[3]; cont = true; }
-      }
-      if (cont) {
-        d = normalized(cross(sub(P[1].v, P[0].v), sub(P[2].v, P[0].v)));
-        if (++guard > 100) return false;
-      } else {
-        it = 0;
-        check_refine = true;
-      }
-    } else if (state == 3) {  // refinement
-      iters++;
-      const double y = dot(s.v, d);
-      if (!(c_is_zero(y) || y > 0) || reach_tol(P, s, d, tol)) return false;
-      expand_portal(P, s);
-      it++;
-      check_refine = true;
-    } else {  // penetration: push the portal to the surface
-      iters++;
-      if (reach_tol(P, s, d, tol) || it > maxit) {
-        V3 w;
-        depth = sqrt(origin_tri_dist2(P[1].v, P[2].v, P[3].v, w));
-        dir = c_is_zero(depth) ? origin : normalized(w);
-        // position from barycentric coordinates of the origin in the portal tetrahedron
-        double bb[4];
-        bb[0] = dot(cross(P[1].v, P[2].v), P[3].v);
-        bb[1] = dot(cross(P[3].v, P[2].v), P[0].v);
-        bb[2] = dot(cross(P[0].v, P[1].v), P[3].v);
-        bb[3] = dot(cross(P[2].v, P[1].v), P[0].v);
-        double sum = bb[0] + bb[1] + bb[2] + bb[3];
-        if (c_is_zero(sum) || sum < 0) {
-          bb[0] = 0;
-          bb[1] = dot(cross(P[2].v, P[3].v), d);
-          bb[2] = dot(cross(P[3].v, P[1].v), d);
-          bb[3] = dot(cross(P[1].v, P[2].v), d);
-          sum = bb[1] + bb[2] + bb[3];
-        }
-        const double inv = 1.0 / sum;
-        V3 p1 = {0, 0, 0}, p2 = {0, 0, 0};
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-          p1.x += bb[i] * P[i].v1.x; p1.y += bb[i] * P[i].v1.y; p1.z += bb[i] * P[i].v1.z;
-          p2.x += bb[i] * P[i].v2.x; p2.y += bb[i] * P[i].v2.y; p2.z += bb[i] * P[i].v2.z;
-        }
-        pos = {0.5 * (p1.x * inv + p2.x * inv), 0.5 * (p1.y * inv + p2.y * inv), 0.5 * (p1.z * inv + p2.z * inv)};
-        return true;
-      }
-      expand_portal(P, s);
-      it++;
-      d = portal_dir(P);
-    }
-    if (check_refine) {
-      if (it > maxit + 1) return false;
-      d = portal_dir(P);
-      const double x = dot(d, P[1].v);
-      if (c_is_zero(x) || x > 0) { it = 0; state = 4; }  // portal encloses the origin ray
-      else state = 3;
-    }
+    const Spt s = md_support(a, b, M.d);
+    const int r = mpr_step(M, s, tol, maxit, depth, dir, pos, iters);
+    if (r) return r == 1;
   }
 }
 
@@ -405,7 +435,10 @@ __device__ inline void col_broadphase(const ColModel& cm, const DevData& d, cons
 }
 
 // A6: one lane per (environment, candidate slot)
-__device__ inline void col_narrowphase(const ColModel& cm, const DevData& d, const ColData& c, long e, int slot) {
+// `acc` (optional): per-lane work counters {pairs, MPR support iterations}; the kernel reduces them
+// over the wavefront before touching ColData::stat (one atomic per wavefront, not per pair)
+__device__ inline void col_narrowphase(const ColModel& cm, const DevData& d, const ColData& c, long e, int slot,
+                                       unsigned* acc = nullptr) {
   const long E = d.E;
   if (slot >= AT(c.ncand, 0)) return;
   const int p = AT(c.cand_pair, slot);
@@ -449,13 +482,161 @@ __device__ inline void col_narrowphase(const ColModel& cm, const DevData& d, con
     if (mpr_penetration(a, b, cm.mpr_tolerance, cm.mpr_iterations, depth, nrm, pos, iters)) {
       if (!(nrm.x == 0 && nrm.y == 0 && nrm.z == 0)) { hit = true; dist = margin - depth; }
     }
-    if (c.stat) { atomicAdd(c.stat, 1ull); atomicAdd(c.stat + 1, (unsigned long long)iters); }
+    if (acc) { acc[0] += 1; acc[1] += (unsigned)iters; }
+    else if (c.stat) { atomicAdd(c.stat, 1ull); atomicAdd(c.stat + 1, (unsigned long long)iters); }
   }
   AT(c.cand_hit, slot) = hit ? 1 : 0;
   if (hit) {
     AT(c.cand_dist, slot) = dist;
     AT(c.cand_pos, 3 * slot) = pos.x; AT(c.cand_pos, 3 * slot + 1) = pos.y; AT(c.cand_pos, 3 * slot + 2) = pos.z;
     AT(c.cand_nrm, 3 * slot) = nrm.x; AT(c.cand_nrm, 3 * slot + 1) = nrm.y; AT(c.cand_nrm, 3 * slot + 2) = nrm.z;
+  }
+}
+
+// A6, work-stealing form: the lanes of a block pull (environment, candidate slot) items from a
+// shared counter and run one loop in which every iteration is ONE batch of four 32-byte record
+// loads (the start-table record or four neighbours of the current vertex) for whichever hull the
+// lane is climbing; MPR transitions and item set-up run in batches when enough lanes wait for
+// them.  Same arithmetic per item as col_narrowphase (climbs start at the table vertex).
+#ifndef NW_BATCH
+#define NW_BATCH 64  // lanes that must wait before a set-up / MPR batch runs while others still climb
+#endif
+__device__ inline void col_narrow_ws(const ColModel& cm, const DevData& d, const ColData& c, long e0, const int* pre,
+                                     int nenv, int* next, unsigned* acc) {
+  const long E = d.E;
+  const int total = pre[nenv];
+  int sub = 0;  // 0 needs an item, 1 climbing, 3 both support points ready, 4 out of items
+  long e = 0;
+  int slot = 0, amesh = 0, bmesh = 0, which = 0, iters = 0;
+  bool plane = false;
+  double margin = 0, infl = 0;
+  V3 ax = {0, 0, 0}, bx = {0, 0, 0}, pn = {0, 0, 0};
+  M3 aR, bR;
+  for (int q = 0; q < 9; q++) { aR.a[q] = 0; bR.a[q] = 0; }
+  MprState M;
+  mpr_begin(M, ax, bx);
+  // climb
+  V3 dloc = {0, 0, 0}, best = {0, 0, 0}, v1 = {0, 0, 0}, v2 = {0, 0, 0};
+  double vmax = 0;
+  int imax = 0, prev = 0, k = 0, kend = 0, bk0 = 0, bdeg = 0;
+  const double4* ptr = cm.hull_nbr4;
+  auto begin_climb = [&](int w) {
+    which = w;
+    const M3& R = w ? bR : aR;
+    const V3 dw = w ? neg(M.d) : M.d;
+    dloc = {R.a[0] * dw.x + R.a[3] * dw.y + R.a[6] * dw.z, R.a[1] * dw.x + R.a[4] * dw.y + R.a[7] * dw.z,
+            R.a[2] * dw.x + R.a[5] * dw.y + R.a[8] * dw.z};
+    ptr = cm.hull_start4 + (size_t)(w ? bmesh : amesh) * BS_NSTART + dir_bin(dloc.x, dloc.y, dloc.z);
+    k = 0; kend = 1; vmax = -1e300; imax = -1; prev = -2;
+  };
+  for (;;) {
+    // ---- item set-up, when enough lanes are idle (or nothing else can run)
+    {
+      const unsigned long long need = __ballot(sub == 0), busy = __ballot(sub == 1);
+      if (need && (__popcll(need) >= NW_BATCH || busy == 0) && sub == 0) {
+        const int item = atomicAdd(next, 1);
+        if (item >= total) sub = 4;
+        else {
+          int lo = 0, hi = nenv;  // largest env index with pre[env] <= item
+          while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (pre[mid] <= item) lo = mid;
+            else hi = mid;
+          }
+          e = e0 + lo; slot = item - pre[lo];
+          const int p = AT(c.cand_pair, slot);
+          const int g1 = cm.pair_geom1[p], g2 = cm.pair_geom2[p];
+          margin = fmax(cm.geom_margin[g1], cm.geom_margin[g2]);
+          bmesh = cm.geom_dataid[g2];
+          bx = {AT(c.geom_xpos, 3 * g2), AT(c.geom_xpos, 3 * g2 + 1), AT(c.geom_xpos, 3 * g2 + 2)};
+          for (int q = 0; q < 9; q++) bR.a[q] = AT(c.geom_xmat, 9 * g2 + q);
+          ax = {AT(c.geom_xpos, 3 * g1), AT(c.geom_xpos, 3 * g1 + 1), AT(c.geom_xpos, 3 * g1 + 2)};
+          plane = cm.geom_type[g1] == BS_GEOM_PLANE;
+          iters = 0;
+          if (plane) {
+            pn = {AT(c.geom_xmat, 9 * g1 + 2), AT(c.geom_xmat, 9 * g1 + 5), AT(c.geom_xmat, 9 * g1 + 8)};
+            infl = 0;
+            M.d = pn;  // hull b is queried along -d
+            begin_climb(1);
+          } else {
+            amesh = cm.geom_dataid[g1];
+            for (int q = 0; q < 9; q++) aR.a[q] = AT(c.geom_xmat, 9 * g1 + q);
+            infl = 0.5 * margin;
+            mpr_begin(M, ax, bx);
+            begin_climb(0);
+          }
+          sub = 1;
+        }
+      }
+    }
+    if (__ballot(sub != 4) == 0) break;
+    // ---- one batch of records for every climbing lane
+    if (sub == 1) {
+      double4 p[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) p[q] = ptr[k + q < kend ? k + q : kend - 1];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const double val = p[q].x * dloc.x + p[q].y * dloc.y + p[q].z * dloc.z;
+        if (val > vmax) {
+          vmax = val; best = {p[q].x, p[q].y, p[q].z};
+          imax = rec_id(p[q].w); bk0 = rec_k0(p[q].w); bdeg = rec_deg(p[q].w);
+        }
+      }
+      k += 4;
+      if (k >= kend) {
+        if (imax != prev && bdeg > 0) {  // moved: scan the new vertex's neighbours
+          prev = imax; ptr = cm.hull_nbr4; k = bk0; kend = bk0 + bdeg;
+        } else {  // local (= global) maximum: world-frame support point of the inflated hull
+          const M3& R = which ? bR : aR;
+          const V3& xp = which ? bx : ax;
+          const V3 dw = which ? neg(M.d) : M.d;
+          const V3 w = mrot(R, best);
+          const V3 sp = {xp.x + w.x + infl * dw.x, xp.y + w.y + infl * dw.y, xp.z + w.z + infl * dw.z};
+          if (which == 0) { v1 = sp; begin_climb(1); }
+          else { v2 = sp; sub = 3; }
+        }
+      }
+    }
+    // ---- MPR transitions, batched
+    {
+      const unsigned long long ready = __ballot(sub == 3), busy = __ballot(sub == 1);
+      if (ready && (__popcll(ready) >= NW_BATCH || busy == 0) && sub == 3) {
+        bool fin = false, hit = false;
+        double dist = 0;
+        V3 pos = {0, 0, 0}, nrm = {0, 0, 0};
+        if (plane) {
+          const double ds = dot(sub3(v2, ax), pn);
+          fin = true;
+          if (!(ds > margin)) {
+            hit = true; dist = ds; nrm = pn;
+            pos = {v2.x - 0.5 * ds * pn.x, v2.y - 0.5 * ds * pn.y, v2.z - 0.5 * ds * pn.z};
+          }
+        } else {
+          Spt s;
+          s.v1 = v1; s.v2 = v2; s.v = sub3(v1, v2);
+          double depth = 0;
+          const int r = mpr_step(M, s, cm.mpr_tolerance, cm.mpr_iterations, depth, nrm, pos, iters);
+          if (r) {
+            fin = true;
+            if (r == 1 && !(nrm.x == 0 && nrm.y == 0 && nrm.z == 0)) { hit = true; dist = margin - depth; }
+            acc[0] += 1; acc[1] += (unsigned)iters;
+          } else {
+            begin_climb(0);
+            sub = 1;
+          }
+        }
+        if (fin) {
+          AT(c.cand_hit, slot) = hit ? 1 : 0;
+          if (hit) {
+            AT(c.cand_dist, slot) = dist;
+            AT(c.cand_pos, 3 * slot) = pos.x; AT(c.cand_pos, 3 * slot + 1) = pos.y; AT(c.cand_pos, 3 * slot + 2) = pos.z;
+            AT(c.cand_nrm, 3 * slot) = nrm.x; AT(c.cand_nrm, 3 * slot + 1) = nrm.y; AT(c.cand_nrm, 3 * slot + 2) = nrm.z;
+          }
+          sub = 0;
+        }
+      }
+    }
   }
 }
 

@@ -604,8 +604,6 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
     }
   }
   // per-lane model constants
-  const V3 bpos = ld3(m.body_pos + 3 * b), jpos = ld3(m.jnt_pos + 3 * j), jax = ld3(m.jnt_axis + 3 * j);
-  const Q4 bquat = ld4(m.body_quat + 4 * b);
   const int jtype = m.jnt_type[j];
   const double mass = isb ? m.body_mass[b] : 0.0, qpos0 = m.qpos0[j];
   const double damping = has_dof ? m.dof_damping[j] : 0.0;
@@ -638,6 +636,10 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
       // ================= forward pass (single inlined site) =================
       // ---- A1 kinematics: joint-local transform first (no parent needed), then one
       // quaternion/vector compose per tree level
+      // pose constants of the lane's body and joint are re-read every step (cache hits) rather
+      // than held in 26 registers across the whole kernel
+      const V3 bpos = ld3(m.body_pos + 3 * b), jpos = ld3(m.jnt_pos + 3 * j), jax = ld3(m.jnt_axis + 3 * j);
+      const Q4 bquat = ld4(m.body_quat + 4 * b);
       const double dq = qpos - qpos0;
       Q4 lq = bquat;
       V3 lp = bpos;
@@ -843,6 +845,22 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
       }
       const double qfrc_smooth = has_dof ? qfrc_passive - qfrc_bias + qfrc_applied + qfrc_actuator : 0.0;
       const double qacc_smooth = tp_solve(c, LM.R, LM.dinv, qfrc_smooth);
+      const bool dump_now = stage == 0 && step == nsteps - 1 && env_ok && dump >= 1;
+      if (dump_now) {
+        // outputs of the step's mj_forward, stored as soon as they exist so they are not kept
+        // alive through the solver (a mj_checkAcc redo simply stores them again)
+        if (l < m.nbody) {
+          AT(d.xpos, 3 * b) = pos.x; AT(d.xpos, 3 * b + 1) = pos.y; AT(d.xpos, 3 * b + 2) = pos.z;
+          AT(d.xquat, 4 * b) = quat.w; AT(d.xquat, 4 * b + 1) = quat.x; AT(d.xquat, 4 * b + 2) = quat.y;
+          AT(d.xquat, 4 * b + 3) = quat.z;
+        }
+        if (has_dof) {
+          AT(d.qfrc_bias, j) = qfrc_bias; AT(d.qfrc_passive, j) = qfrc_passive;
+          AT(d.qfrc_actuator, j) = qfrc_actuator; AT(d.qfrc_smooth, j) = qfrc_smooth;
+          AT(d.qacc_smooth, j) = qacc_smooth;
+        }
+        if (act >= 0) AT(d.actuator_force, act) = act_force;
+      }
 
       TPC_T(1)
       // ---- contacts (k_tpc): ordered hit compaction (same arithmetic as col_assemble) and the
@@ -1317,18 +1335,7 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
         continue;
       }
       if (stage == 0 && step == nsteps - 1 && env_ok && dump >= 1) {
-        // outputs of the step's mj_forward (MuJoCo leaves these from before the integration)
-        if (l < m.nbody) {
-          AT(d.xpos, 3 * b) = pos.x; AT(d.xpos, 3 * b + 1) = pos.y; AT(d.xpos, 3 * b + 2) = pos.z;
-          AT(d.xquat, 4 * b) = quat.w; AT(d.xquat, 4 * b + 1) = quat.x; AT(d.xquat, 4 * b + 2) = quat.y;
-          AT(d.xquat, 4 * b + 3) = quat.z;
-        }
-        if (has_dof) {
-          AT(d.qfrc_bias, j) = qfrc_bias; AT(d.qfrc_passive, j) = qfrc_passive;
-          AT(d.qfrc_actuator, j) = qfrc_actuator; AT(d.qfrc_smooth, j) = qfrc_smooth;
-          AT(d.qacc_smooth, j) = qacc_smooth; AT(d.qfrc_constraint, j) = qfrc_constraint;
-        }
-        if (act >= 0) AT(d.actuator_force, act) = act_force;
+        if (has_dof) AT(d.qfrc_constraint, j) = qfrc_constraint;
         if (FULL && dump >= 2) {
           if (l < m.nbody) {
             AT(d.xipos, 3 * b) = xipos.x; AT(d.xipos, 3 * b + 1) = xipos.y; AT(d.xipos, 3 * b + 2) = xipos.z;

@@ -37,3 +37,27 @@ def contact_free(model):
     m = model.copy()
     m.opt_disableflags = int(m.opt_disableflags) | DSBL_CONTACT
     return m
+
+
+def with_ground_plane(model, z=-0.05):
+    """BASELINE.json configs[2] / SURVEY.md §8(d) config 3: the exported XML plus a ground plane
+    `<geom type="plane" size="0 0 1" pos="0 0 z"/>` on the world body.  The plane is NOT in the
+    reference XML; it is this build's augmentation and every report says so."""
+    from .model import GEOM_PLANE
+    m = model.copy()
+
+    def app(a, v):
+        return np.concatenate([a, np.asarray(v, dtype=a.dtype).reshape((1,) + a.shape[1:])])
+
+    m.geom_type = app(m.geom_type, GEOM_PLANE); m.geom_bodyid = app(m.geom_bodyid, 0)
+    m.geom_dataid = app(m.geom_dataid, -1); m.geom_contype = app(m.geom_contype, 1)
+    m.geom_conaffinity = app(m.geom_conaffinity, 1); m.geom_condim = app(m.geom_condim, 3)
+    m.geom_priority = app(m.geom_priority, 0); m.geom_pos = app(m.geom_pos, [0, 0, z])
+    m.geom_quat = app(m.geom_quat, [1, 0, 0, 0]); m.geom_size = app(m.geom_size, [0, 0, 1])
+    m.geom_friction = app(m.geom_friction, [1, 0.005, 0.0001]); m.geom_margin = app(m.geom_margin, 0.0)
+    m.geom_gap = app(m.geom_gap, 0.0); m.geom_solref = app(m.geom_solref, [0.02, 1])
+    m.geom_solimp = app(m.geom_solimp, [0.9, 0.95, 0.001, 0.5, 2]); m.geom_solmix = app(m.geom_solmix, 1.0)
+    m.geom_rbound = app(m.geom_rbound, 0.0)
+    m.geom_names = list(m.geom_names) + ["ground_plane"]
+    m._build_pairs()
+    return m

@@ -322,23 +322,8 @@ def test_ground_plane_contact(hand_model):
     from mujoco_amd import BatchSim
     from mujoco_amd.model import GEOM_PLANE
     from oracle import OracleSim
-    m = hand_model.copy()
-    # append a plane geom on the world body just below the lowest finger pose reach
-    import numpy as np
-    def app(a, v):
-        return np.concatenate([a, np.asarray(v, dtype=a.dtype).reshape((1,) + a.shape[1:])])
-    g = m.ngeom
-    m.geom_type = app(m.geom_type, GEOM_PLANE); m.geom_bodyid = app(m.geom_bodyid, 0)
-    m.geom_dataid = app(m.geom_dataid, -1); m.geom_contype = app(m.geom_contype, 1)
-    m.geom_conaffinity = app(m.geom_conaffinity, 1); m.geom_condim = app(m.geom_condim, 3)
-    m.geom_priority = app(m.geom_priority, 0); m.geom_pos = app(m.geom_pos, [0, 0, -0.06])
-    m.geom_quat = app(m.geom_quat, [1, 0, 0, 0]); m.geom_size = app(m.geom_size, [0, 0, 1])
-    m.geom_friction = app(m.geom_friction, [1, 0.005, 0.0001]); m.geom_margin = app(m.geom_margin, 0.0)
-    m.geom_gap = app(m.geom_gap, 0.0); m.geom_solref = app(m.geom_solref, [0.02, 1])
-    m.geom_solimp = app(m.geom_solimp, [0.9, 0.95, 0.001, 0.5, 2]); m.geom_solmix = app(m.geom_solmix, 1.0)
-    m.geom_rbound = app(m.geom_rbound, 0.0)
-    m.geom_names = m.geom_names + ["ground_plane"]
-    m._build_pairs()
+    from mujoco_amd import workload
+    m = workload.with_ground_plane(hand_model, z=-0.06)
     assert m.npair > 210
     sim = BatchSim(m, n_envs=2)
     s = OracleSim(m)
@@ -350,6 +335,37 @@ def test_ground_plane_contact(hand_model):
     want = sorted((cc["geom1"], cc["geom2"]) for cc in s.contacts())
     got = sorted((g1, g2) for g1, g2, _ in sim.data.contacts(1))
     assert got == want
+    assert any(g1 == m.ngeom - 1 for g1, _ in want)  # the plane really is touched
+    # the same through bs_step (tree-parallel contact kernel: the plane's body is the world lane)
+    sim.step(2); sim.sync(); s.step(2)
+    assert np.abs(sim.data.qpos.cpu().numpy()[1] - s.qpos).max() < 1e-10
+    err = np.abs(sim.data.qacc.cpu().numpy()[1] - s.qacc).max() / max(1.0, np.abs(s.qacc).max())
+    assert err < 1e-8, err
+
+
+def test_work_stealing_narrowphase(hand_model, monkeypatch):
+    """BS_NARROW=ws (opt-in variant of the narrowphase) finds the same contacts as the default."""
+    import torch
+    from mujoco_amd import BatchSim, workload
+    m = _contact_model(hand_model)
+    E = 200
+    q, v = workload.config2_state(m, E, seed=99)
+    c = workload.config2_ctrl(m, E, seed=99)
+    res = {}
+    for mode in ("flat", "ws"):
+        monkeypatch.setenv("BS_NARROW", mode)
+        sim = BatchSim(m, n_envs=E)
+        sim.data.qpos.copy_(torch.as_tensor(q)); sim.data.ctrl.copy_(torch.as_tensor(c))
+        sim.step(2); sim.sync()
+        res[mode] = (sim.data.qacc.cpu().numpy().copy(), sim.data.ncon.cpu().numpy().copy(),
+                     [sorted(sim.data.contacts(e)) for e in range(0, E, 7)])
+        del sim
+    monkeypatch.delenv("BS_NARROW")
+    assert (res["flat"][1] == res["ws"][1]).all() and res["flat"][1].sum() > 100
+    for a, b in zip(res["flat"][2], res["ws"][2]):
+        assert [(x[0], x[1]) for x in a] == [(x[0], x[1]) for x in b]
+        assert all(abs(x[2] - y[2]) < 1e-9 for x, y in zip(a, b))
+    assert np.abs(res["flat"][0] - res["ws"][0]).max() < 1e-6 * max(1.0, np.abs(res["flat"][0]).max())
 
 
 @pytest.mark.parametrize("contacts", [False, True])
