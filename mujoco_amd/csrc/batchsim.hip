@@ -596,7 +596,15 @@ __global__ __launch_bounds__(64, 2) void k_tp(DevModel m, TpModel t, DevData d, 
   const TpShared sh = {tbl, nullptr, nullptr, nullptr};
   ColModel cm;
   ColData cd;
-  tp_run<false, false>(m, t, d, nsteps, mode, dump, sh, cm, cd);
+  tp_run<false, false, false>(m, t, d, nsteps, mode, dump, sh, cm, cd);
+}
+// same with the RK4 integrator (three extra forward passes per step)
+__global__ __launch_bounds__(64, 2) void k_tp_rk4(DevModel m, TpModel t, DevData d, int nsteps, int mode, int dump) {
+  __shared__ int tbl[TPL_TOTAL * 64];
+  const TpShared sh = {tbl, nullptr, nullptr, nullptr};
+  ColModel cm;
+  ColData cd;
+  tp_run<false, false, true>(m, t, d, nsteps, mode, dump, sh, cm, cd);
 }
 // same, with every intermediate the parity tests read written out (bs_forward)
 __global__ __launch_bounds__(64, 2) void k_tp_full(DevModel m, TpModel t, DevData d, int nsteps, int mode, int dump) {
@@ -604,7 +612,7 @@ __global__ __launch_bounds__(64, 2) void k_tp_full(DevModel m, TpModel t, DevDat
   const TpShared sh = {tbl, nullptr, nullptr, nullptr};
   ColModel cm;
   ColData cd;
-  tp_run<false, true>(m, t, d, nsteps, mode, dump, sh, cm, cd);
+  tp_run<false, true, false>(m, t, d, nsteps, mode, dump, sh, cm, cd);
 }
 // kinematics + geom frames + broadphase, tree-parallel layout (physics_tp.h::tp_collide_prep)
 __global__ __launch_bounds__(64) void k_tp_col(DevModel m, TpModel t, DevData d, ColModel cm, ColData cd) {
@@ -622,7 +630,7 @@ __global__ __launch_bounds__(64, TPC_OCC) void k_tpc(DevModel m, TpModel t, DevD
   extern __shared__ double tpc_dyn[];
   const int ntri = m.nbody * (m.nbody + 1) / 2;
   const TpShared sh = {tbl, tpc_dyn, tpc_dyn + 2 * ntri, tpc_dyn + 2 * ntri + 2 * TP_LPE * TPC_SLOT};
-  tp_run<true, false>(m, t, d, 1, mode, dump, sh, cm, cd);
+  tp_run<true, false, false>(m, t, d, 1, mode, dump, sh, cm, cd);
 }
 __global__ __launch_bounds__(BS_BLOCK) void k_forward(DevModel m, DevData d) {
   const long e = (long)blockIdx.x * BS_BLOCK + threadIdx.x;
@@ -825,7 +833,8 @@ static void launch_step(bs_sim* s, int n_steps) {
     return;
   }
   if (s->use_tp)
-    hipLaunchKernelGGL(k_tp, grid_tp(s), dim3(64), 0, s->stream, s->dm, s->tp, s->dd, n_steps, 0, 1);
+    hipLaunchKernelGGL(s->dm.integrator == 1 ? k_tp_rk4 : k_tp, grid_tp(s), dim3(64), 0, s->stream, s->dm, s->tp, s->dd,
+                       n_steps, 0, 1);
   else
     hipLaunchKernelGGL(k_step, grid_for(s), dim3(BS_BLOCK), 0, s->stream, s->dm, s->dd, n_steps);
 }

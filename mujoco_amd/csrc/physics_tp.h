@@ -551,7 +551,7 @@ __device__ __forceinline__ void tp_collide_prep(const DevModel& m, const TpModel
 // generalized forces of the last forward pass, 2: every intermediate the parity tests read.
 // CON: one step per launch with the contact candidates of k_c_broad / k_c_narrow (physics_collide.h):
 // contact assembly, pyramid rows owned by lanes, dense Hessian per environment in LDS.
-template <bool CON, bool FULL>
+template <bool CON, bool FULL, bool RK4>
 __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, const DevData& d, int nsteps,
                                        int mode, int dump, TpShared sh, const ColModel& cm, const ColData& cd) {
   int* tbl = sh.tbl;
@@ -623,7 +623,7 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
   };
 
   TPC_T(0)
-  const int nstage = (mode == 0 && m.integrator == 1) ? 4 : 1;
+  const int nstage = (RK4 && mode == 0) ? 4 : 1;  // RK4: the host picks the instantiation from opt.integrator
   for (int step = 0; step < nsteps; step++) {
     if (mode == 0) {  // A14 mj_checkPos / mj_checkVel
       if (env_any(has_dof && bad_num(qpos), base)) { reset_state(); warning |= 1; }
@@ -671,6 +671,12 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
           const double inv = 1.0 / sqrt(n2);
           quat.w *= inv; quat.x *= inv; quat.y *= inv; quat.z *= inv;
         }
+      }
+      if (!FULL && stage == 0 && step == nsteps - 1 && env_ok && dump >= 1 && l < m.nbody) {
+        // body poses are outputs of the step: stored here so they need not stay live
+        AT(d.xpos, 3 * b) = pos.x; AT(d.xpos, 3 * b + 1) = pos.y; AT(d.xpos, 3 * b + 2) = pos.z;
+        AT(d.xquat, 4 * b) = quat.w; AT(d.xquat, 4 * b + 1) = quat.x; AT(d.xquat, 4 * b + 2) = quat.y;
+        AT(d.xquat, 4 * b + 3) = quat.z;
       }
       const M3 xmat = q2m(quat);
       V3 axis = mrot(xmat, jax), anchor;
@@ -849,11 +855,6 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
       if (dump_now) {
         // outputs of the step's mj_forward, stored as soon as they exist so they are not kept
         // alive through the solver (a mj_checkAcc redo simply stores them again)
-        if (l < m.nbody) {
-          AT(d.xpos, 3 * b) = pos.x; AT(d.xpos, 3 * b + 1) = pos.y; AT(d.xpos, 3 * b + 2) = pos.z;
-          AT(d.xquat, 4 * b) = quat.w; AT(d.xquat, 4 * b + 1) = quat.x; AT(d.xquat, 4 * b + 2) = quat.y;
-          AT(d.xquat, 4 * b + 3) = quat.z;
-        }
         if (has_dof) {
           AT(d.qfrc_bias, j) = qfrc_bias; AT(d.qfrc_passive, j) = qfrc_passive;
           AT(d.qfrc_actuator, j) = qfrc_actuator; AT(d.qfrc_smooth, j) = qfrc_smooth;
@@ -1336,6 +1337,11 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
       }
       if (stage == 0 && step == nsteps - 1 && env_ok && dump >= 1) {
         if (has_dof) AT(d.qfrc_constraint, j) = qfrc_constraint;
+        if (FULL && l < m.nbody) {
+          AT(d.xpos, 3 * b) = pos.x; AT(d.xpos, 3 * b + 1) = pos.y; AT(d.xpos, 3 * b + 2) = pos.z;
+          AT(d.xquat, 4 * b) = quat.w; AT(d.xquat, 4 * b + 1) = quat.x; AT(d.xquat, 4 * b + 2) = quat.y;
+          AT(d.xquat, 4 * b + 3) = quat.z;
+        }
         if (FULL && dump >= 2) {
           if (l < m.nbody) {
             AT(d.xipos, 3 * b) = xipos.x; AT(d.xipos, 3 * b + 1) = xipos.y; AT(d.xipos, 3 * b + 2) = xipos.z;
@@ -1366,7 +1372,7 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
       }
       TPC_T(17)
       if (mode == 1) break;
-      if (nstage == 1) {
+      if (!RK4) {
         // ---- A12 Euler with implicit joint damping
         double acc = qacc;
         if (m.damped) {
