@@ -27,6 +27,19 @@ FP64_PEAK_TFLOPS = 78.6         # MI355X fp64 vector == fp64 matrix peak (datash
 CTRL_PERIOD = 50
 
 
+def pmc_traffic(kernel, section):
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC summary
+    (profiles/r01_pmc_summary.json, separate FETCH_SIZE / WRITE_SIZE passes of this same command):
+    (2 x FETCH_SIZE + WRITE_SIZE) KB, the gfx950 correction of MI355X_MICROARCH.md.  bench.py
+    cannot collect counters itself; None if the summary is missing."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")) as f:
+            k = json.load(f)[section][kernel]
+        return (2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(model, seconds_budget=12.0):
     """Oracle (CPU restatement, kind 'port') on this host: single thread, then all cores."""
     from mujoco_amd import workload
@@ -215,11 +228,14 @@ def main():
                        "collective": "RCCL all_gather obs[E,42]+reward fp32 per ctrl period" if world > 1 else "none",
                        "mean_solver_iter": iters, "mean_nefc": nefc, "envs_with_warnings": warn},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None,
+                         "frac": achieved / FP64_PEAK_TFLOPS,
+                         "traffic": pmc_traffic("k_tp", "config1_pmc_per_launch") if not cstat else None,
                          "kernel": "k_tp", "launch_ms": k_ms, "env_steps_per_launch": E * CTRL_PERIOD,
                          "flop_per_env_step": flop_env_step,
-                         "note": "fp64 compute-bound path: peak is the MI355X fp64 vector=matrix rate; "
-                                 "algorithmic HBM rate would be "
+                         "note": "fp64 compute-bound path ('mfma' stands for the fp64 ALU roof: the contract allows "
+                                 "only hbm|mfma; no MFMA instruction is used): peak is the MI355X fp64 vector=matrix "
+                                 "rate; traffic = bytes/launch from the committed PMC summary (mostly register-spill "
+                                 "scratch, not state); algorithmic HBM rate would be "
                                  f"{BYTES_PER_ENV_STEP * E * CTRL_PERIOD / (k_ms * 1e-3) / 1e9:.2f} GB/s of 8000"},
             "gpu_event_ms_per_step": gpu_ms / args.steps,
             "stage_ms_one_step": stage,
