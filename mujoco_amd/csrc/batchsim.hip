@@ -194,8 +194,8 @@ extern "C" int bs_model_create(const bs_model_desc* desc, bs_model** out) {
     return fail(BS_ERR_INVALID, "bs_model_create: inconsistent sizes (nbody=%d njnt=%d nv=%d nM=%d)", nb,
                 nj, nv, desc->nM);
   if (!(desc->timestep > 0)) return fail(BS_ERR_INVALID, "bs_model_create: timestep must be > 0");
-  if (desc->solver != 2 && desc->solver != 0)
-    return fail(BS_ERR_UNSUPPORTED, "bs_model_create: solver %d is not implemented (0 = PGS, 2 = Newton)",
+  if (desc->solver < 0 || desc->solver > 2)
+    return fail(BS_ERR_UNSUPPORTED, "bs_model_create: solver %d is not implemented (0 = PGS, 1 = CG, 2 = Newton)",
                 desc->solver);
   if (desc->integrator != 0 && desc->integrator != 1)
     return fail(BS_ERR_INVALID, "bs_model_create: integrator must be 0 (Euler) or 1 (RK4)");

@@ -141,9 +141,10 @@ __device__ inline double cost_at_c(const DevModel& m, const DevData& d, const Co
 // factorisation is otherwise bound by L2/HBM traffic).
 #define HDX(q) (*(hs ? hs + (size_t)(q) * 64 + threadIdx.x : &AT(k.Hd, q)))
 __device__ inline double update_gradient_dense(const DevModel& m, const DevData& d, const ConData& k, long e,
-                                               int ncrow, double* hs) {
+                                               int ncrow, double* hs, bool first = true) {
   const long E = d.E;
   const int nv = m.nv;
+  if (m.solver == 1) return cg_gradient(m, d, e, first);
   double gg = 0;
   for (int i = 0; i < nv; i++) {
     const double g = AT(d.Ma, i) - AT(d.qfrc_smooth, i) - AT(d.qfrc_constraint, i);
@@ -360,7 +361,7 @@ __device__ inline void stage_constraint_c(const DevModel& m, const ColModel& cm,
     for (int r = 0; r < ncrow; r++) AT(k.cjar, r) += alpha * AT(k.cjv, r);
     const double oldcost = cost;
     cost = update(gauss);
-    const double gg = update_gradient_dense(m, d, k, e, ncrow, hs);
+    const double gg = update_gradient_dense(m, d, k, e, ncrow, hs, false);
     iter++;
     const double improvement = scale * (oldcost - cost), gradient = scale * sqrt(gg);
     if (improvement < m.tolerance || gradient < m.tolerance) break;

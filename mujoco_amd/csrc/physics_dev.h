@@ -587,8 +587,35 @@ __device__ inline double cost_at(const DevModel& m, const DevData& d, long e, co
 
 // grad = Ma - qfrc_smooth - qfrc_constraint;  H = M + J^T D_active J on the dof-tree sparsity
 // (every fixed row touches dofs on one root path), factorised like M;  search = -H^-1 grad
-__device__ inline double update_gradient(const DevModel& m, const DevData& d, long e) {
+// mj_solCG's direction: Mgrad = M^-1 grad (the preconditioner is M), Polak-Ribiere beta clamped
+// at 0 in the M^-1 inner product; shares the primal loop, line search and stopping rule with
+// Newton.  d.Mv holds the previous Mgrad while the new one is formed (it is free outside the
+// line search).
+__device__ inline double cg_gradient(const DevModel& m, const DevData& d, long e, bool first) {
   const long E = d.E;
+  double gg = 0, gg_old = 0;
+  for (int i = 0; i < m.nv; i++) {
+    if (!first) { gg_old += AT(d.grad, i) * AT(d.Mgrad, i); AT(d.Mv, i) = AT(d.Mgrad, i); }
+    const double g = AT(d.Ma, i) - AT(d.qfrc_smooth, i) - AT(d.qfrc_constraint, i);
+    AT(d.grad, i) = g;
+    AT(d.Mgrad, i) = g;
+    gg += g * g;
+  }
+  solve_sparse(m, d.qLD, d.qLDiagInv, d.Mgrad, E, e);
+  double beta = 0;
+  if (!first) {
+    double num = 0;
+    for (int i = 0; i < m.nv; i++) num += AT(d.grad, i) * (AT(d.Mgrad, i) - AT(d.Mv, i));
+    beta = num / (gg_old > BS_MINVAL ? gg_old : BS_MINVAL);
+    if (beta < 0) beta = 0;
+  }
+  for (int i = 0; i < m.nv; i++) AT(d.search, i) = -AT(d.Mgrad, i) + (first ? 0.0 : beta * AT(d.search, i));
+  return gg;
+}
+
+__device__ inline double update_gradient(const DevModel& m, const DevData& d, long e, bool first = true) {
+  const long E = d.E;
+  if (m.solver == 1) return cg_gradient(m, d, e, first);
   double gg = 0;
   for (int i = 0; i < m.nv; i++) {
     const double g = AT(d.Ma, i) - AT(d.qfrc_smooth, i) - AT(d.qfrc_constraint, i);
@@ -762,7 +789,7 @@ __device__ inline void stage_constraint(const DevModel& m, const DevData& d, lon
       gauss += (AT(d.Ma, i) - AT(d.qfrc_smooth, i)) * (AT(d.qacc, i) - AT(d.qacc_smooth, i));
     gauss *= 0.5;
     cost = gauss + rows_update<true>(m, d, e, d.jar);
-    const double gg = update_gradient(m, d, e);
+    const double gg = update_gradient(m, d, e, false);
     iter++;
     const double improvement = scale * (oldcost - cost), gradient = scale * sqrt(gg);
     if (improvement < m.tolerance || gradient < m.tolerance) break;

@@ -782,6 +782,11 @@ static void sol_update_gradient(solctx *c) {
   orc_data *d = c->d;
   int nv = c->nv;
   for (int k = 0; k < nv; k++) c->grad[k] = c->Ma[k] - d->qfrc_smooth[k] - d->qfrc_constraint[k];
+  if (m->solver == SOL_CG) { /* mj_solCG: the preconditioner is M itself, Mgrad = M^-1 grad */
+    memcpy(c->Mgrad, c->grad, sizeof(double) * nv);
+    orc_solve_m(m, d, c->Mgrad);
+    return;
+  }
   /* H = M + J^T diag(D_active) J */
   orc_full_m(m, d, c->H);
   for (int i = 0; i < d->nefc; i++) {
@@ -885,6 +890,9 @@ static double line_search(solctx *c) {
   return best.cost < p0.cost ? best.alpha : 0.0;
 }
 
+/* mj_solNewton and mj_solCG share the primal loop (mj_solPrimal shape [EXT]): Newton searches
+ * along -H^-1 grad, CG along -M^-1 grad + beta * previous direction with the Polak-Ribiere beta
+ * (clamped at 0) in the M^-1 inner product */
 static void sol_newton(const orc_model *m, orc_data *d) {
   int nv = m->nv, nefc = d->nefc;
   solctx c;
@@ -902,15 +910,29 @@ static void sol_newton(const orc_model *m, orc_data *d) {
   sol_update_gradient(&c);
   for (int k = 0; k < nv; k++) c.search[k] = -c.Mgrad[k];
   int iter = 0;
+  double oldgrad[nv > 0 ? nv : 1], oldMgrad[nv > 0 ? nv : 1]; /* CG only */
   while (iter < m->iterations) {
     double alpha = line_search(&c);
     if (alpha == 0) break;
     for (int k = 0; k < nv; k++) { d->qacc[k] += alpha * c.search[k]; c.Ma[k] += alpha * c.Mv[k]; }
     for (int i = 0; i < nefc; i++) c.jar[i] += alpha * c.jv[i];
     double oldcost = c.cost;
+    double gg_old = 0;
+    if (m->solver == SOL_CG) {
+      memcpy(oldgrad, c.grad, sizeof(double) * nv);
+      memcpy(oldMgrad, c.Mgrad, sizeof(double) * nv);
+      gg_old = dotn(oldgrad, oldMgrad, nv);
+    }
     sol_update_constraint(&c);
     sol_update_gradient(&c);
-    for (int k = 0; k < nv; k++) c.search[k] = -c.Mgrad[k];
+    if (m->solver == SOL_CG) {
+      double num = 0;
+      for (int k = 0; k < nv; k++) num += c.grad[k] * (c.Mgrad[k] - oldMgrad[k]);
+      double beta = num / (gg_old > MINVAL ? gg_old : MINVAL);
+      if (beta < 0) beta = 0;
+      for (int k = 0; k < nv; k++) c.search[k] = -c.Mgrad[k] + beta * c.search[k];
+    } else
+      for (int k = 0; k < nv; k++) c.search[k] = -c.Mgrad[k];
     iter++;
     double improvement = c.scale * (oldcost - c.cost);
     double gradient = c.scale * sqrt(dotn(c.grad, c.grad, nv));
@@ -998,7 +1020,7 @@ void orc_fwd_constraint(const orc_model *m, orc_data *d) {
     memcpy(d->qacc, cw > cs ? d->qacc_smooth : d->qacc_warmstart, sizeof(double) * nv);
   } else
     memcpy(d->qacc, d->qacc_smooth, sizeof(double) * nv);
-  sol_newton(m, d); /* Newton is the reference default (no <option> in the XML); CG is not restated */
+  sol_newton(m, d); /* Newton is the reference default (no <option> in the XML); SOL_CG takes the CG branches */
   memcpy(d->qacc_warmstart, d->qacc, sizeof(double) * nv);
 }
 

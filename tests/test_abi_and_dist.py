@@ -36,7 +36,7 @@ def test_model_desc_validation_without_gpu(hand_model):
     from mujoco_amd.sim import NativeModel
     NativeModel(workload.contact_free(hand_model))  # valid
     bad = hand_model.copy()
-    bad.opt_solver = 1
+    bad.opt_solver = 7
     with pytest.raises(_abi.BatchSimError, match="not implemented"):
         NativeModel(bad)
     bad = hand_model.copy()

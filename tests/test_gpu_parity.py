@@ -201,7 +201,7 @@ def test_error_behaviour(hand_model):
     with pytest.raises(BatchSimError):
         sim.step(-1)
     bad = m.copy()
-    bad.opt_solver = 1  # CG is not implemented
+    bad.opt_solver = 7  # no such solver
     with pytest.raises(BatchSimError):
         BatchSim(bad, n_envs=1)
 
@@ -366,6 +366,40 @@ def test_work_stealing_narrowphase(hand_model, monkeypatch):
         assert [(x[0], x[1]) for x in a] == [(x[0], x[1]) for x in b]
         assert all(abs(x[2] - y[2]) < 1e-9 for x, y in zip(a, b))
     assert np.abs(res["flat"][0] - res["ws"][0]).max() < 1e-6 * max(1.0, np.abs(res["flat"][0]).max())
+
+
+@pytest.mark.parametrize("contacts", [False, True])
+def test_cg_matches_oracle(hand_model, contacts):
+    """solver=CG (mj_solCG: Polak-Ribiere with M^-1 as preconditioner, shared primal loop): device vs
+    oracle, iteration counts equal within one, and both at the Newton fixed point."""
+    import torch
+    from mujoco_amd import BatchSim, workload
+    from mujoco_amd.model import SOL_CG, SOL_NEWTON
+    m = hand_model.copy() if contacts else workload.contact_free(hand_model)
+    m.opt_solver = SOL_CG
+    E = 64
+    q, v = workload.config2_state(m, E, seed=1236)
+    c = workload.config2_ctrl(m, E, seed=1236)
+    sim = BatchSim(m, n_envs=E)
+    sim.data.qpos.copy_(torch.as_tensor(q))
+    sim.data.ctrl.copy_(torch.as_tensor(c))
+    sim.forward()
+    sim.sync()
+    qacc = sim.data.qacc.cpu().numpy()
+    it = sim.data.solver_iter.cpu().numpy()
+    mn = m.copy()
+    mn.opt_solver = SOL_NEWTON
+    for e in range(0, E, 7):
+        ref, s = _oracle_forward(m, q[e], v[e], c[e], ["qacc"])
+        sc = max(1.0, np.abs(ref["qacc"]).max())
+        assert np.abs(qacc[e] - ref["qacc"]).max() / sc < 1e-8, e
+        assert abs(int(it[e]) - s.solver_iter) <= 1
+        newton, _ = _oracle_forward(mn, q[e], v[e], c[e], ["qacc"])
+        assert np.abs(qacc[e] - newton["qacc"]).max() / sc < 1e-4, e
+    sim.step(100)
+    sim.sync()
+    assert np.isfinite(sim.data.qpos.cpu().numpy()).all()
+    assert sim.data.warning.cpu().numpy().max() == 0
 
 
 @pytest.mark.parametrize("contacts", [False, True])

@@ -216,3 +216,29 @@ def test_pgs_newton_same_fixed_point(hand_model):
                 s.qpos[:] = q[e]
                 s.forward()
             assert np.abs(a.qacc - b.qacc).max() < 1e-5 * max(1.0, np.abs(a.qacc).max())
+
+
+def test_cg_matches_newton(hand_model):
+    """mj_solCG restatement: same minimiser as Newton on the same convex cost (tight tolerance),
+    with and without contact rows; more iterations than Newton, as expected of a first-order method."""
+    from mujoco_amd import workload
+    from mujoco_amd.model import SOL_CG, SOL_NEWTON
+    from oracle import OracleSim
+    q, v = workload.config2_state(hand_model, 4, seed=5)
+    c = workload.config2_ctrl(hand_model, 4, seed=5)
+    for contacts in (False, True):
+        base = hand_model if contacts else workload.contact_free(hand_model)
+        out = {}
+        for sol in (SOL_NEWTON, SOL_CG):
+            m = base.copy()
+            m.opt_solver = sol
+            m.opt_tolerance = 1e-12
+            m.opt_iterations = 500
+            s = OracleSim(m)
+            s.qpos[:] = q[1]
+            s.ctrl[:] = c[1]
+            s.forward()
+            out[sol] = (np.array(s.qacc).copy(), s.solver_iter)
+        err = np.abs(out[SOL_CG][0] - out[SOL_NEWTON][0]).max() / np.abs(out[SOL_NEWTON][0]).max()
+        assert err < 1e-7, (contacts, err)
+        assert out[SOL_CG][1] >= out[SOL_NEWTON][1]
