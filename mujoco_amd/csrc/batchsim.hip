@@ -669,6 +669,19 @@ __global__ __launch_bounds__(BS_BLOCK) void k_reset(DevModel m, DevData d, const
   const long E = d.E;
   AT(d.warning, 0) = 0;
 }
+// A14 mj_checkPos / mj_checkVel on their own (the RK4 step with contacts starts with it)
+__global__ __launch_bounds__(BS_BLOCK) void k_check_state(DevModel m, DevData d) {
+  const long e = (long)blockIdx.x * BS_BLOCK + threadIdx.x;
+  if (e >= d.n_envs) return;
+  env_check(m, d, e, d.qpos, m.njnt, 0);
+  env_check(m, d, e, d.qvel, m.nv, 1);
+}
+// RK4 across launches (contacts): see rk4_advance
+__global__ __launch_bounds__(BS_BLOCK) void k_rk4_advance(DevModel m, DevData d, int i) {
+  const long e = (long)blockIdx.x * BS_BLOCK + threadIdx.x;
+  if (e >= d.n_envs) return;
+  rk4_advance(m, d, e, i);
+}
 // on-demand frames: xmat[9*nbody], geom_xpos[3*ngeom], geom_xmat[9*ngeom] from xpos/xquat
 __global__ __launch_bounds__(BS_BLOCK) void k_frames(DevModel m, DevData d, double* xmat, double* gpos,
                                                      double* gmat) {
@@ -807,9 +820,13 @@ static void launch_narrow(bs_sim* s) {
   else
     hipLaunchKernelGGL(k_c_narrow_flat, g, dim3(NB_THREADS), 0, s->stream, s->cm, s->dd, s->cd);
 }
-static void launch_contact_pass(bs_sim* s, int check, int integrate, int dump = 1) {
+// check: mj_checkPos/Vel first; integrate: mj_step (Euler) rather than mj_forward; fast: let the
+// tree-parallel kernels run a forward pass too (they leave the position-stage intermediates of
+// bs_forward unwritten, which the RK4 stages do not need)
+static void launch_contact_pass(bs_sim* s, int check, int integrate, int dump = 1, int fast = 0) {
   const dim3 g = dim3((unsigned)((s->n_envs + BS_BLOCK - 1) / BS_BLOCK));
-  if (s->use_tpc && integrate) {
+  const bool tp = s->use_tpc && (integrate || fast);
+  if (tp) {
     const size_t lds = (size_t)2 * s->cm.ngeom * TPG_SLOT * sizeof(double);
     hipLaunchKernelGGL(k_tp_col, grid_tp(s), dim3(64), lds, s->stream, s->dm, s->tp, s->dd, s->cm, s->cd);
   } else {
@@ -817,10 +834,10 @@ static void launch_contact_pass(bs_sim* s, int check, int integrate, int dump = 
     hipLaunchKernelGGL(k_c_broad, dim3((unsigned)s->n_envs), dim3(64), 0, s->stream, s->cm, s->dd, s->cd);
   }
   launch_narrow(s);
-  if (s->use_tpc && integrate) {
+  if (tp) {
     const int ntri = s->dm.nbody * (s->dm.nbody + 1) / 2;
     const size_t lds = (size_t)(2 * ntri + 2 * TP_LPE * TPC_SLOT + 2 * TP_LPE * 3) * sizeof(double);
-    hipLaunchKernelGGL(k_tpc, grid_tp(s), dim3(64), lds, s->stream, s->dm, s->tp, s->dd, s->cm, s->cd, 0, dump);
+    hipLaunchKernelGGL(k_tpc, grid_tp(s), dim3(64), lds, s->stream, s->dm, s->tp, s->dd, s->cm, s->cd, integrate ? 0 : 1, dump);
     return;
   }
   hipLaunchKernelGGL(k_c_dyn, g, dim3(BS_BLOCK), s->hs_bytes, s->stream, s->dm, s->cm, s->dd, s->cd, s->kd, integrate,
@@ -829,6 +846,15 @@ static void launch_contact_pass(bs_sim* s, int check, int integrate, int dump = 
 static void launch_step(bs_sim* s, int n_steps) {
   if (s->contacts) {
     // outputs of the forward pass (poses, generalized forces) are only observable after the last step
+    if (s->dm.integrator == 1) {  // RK4: four forward passes (collision included), state moved in between
+      for (int k = 0; k < n_steps; k++)
+        for (int i = 1; i <= 4; i++) {
+          if (i == 1) hipLaunchKernelGGL(k_check_state, grid_for(s), dim3(BS_BLOCK), 0, s->stream, s->dm, s->dd);
+          launch_contact_pass(s, 0, 0, i == 4 && k == n_steps - 1, 1);
+          hipLaunchKernelGGL(k_rk4_advance, grid_for(s), dim3(BS_BLOCK), 0, s->stream, s->dm, s->dd, i);
+        }
+      return;
+    }
     for (int k = 0; k < n_steps; k++) launch_contact_pass(s, 1, 1, k == n_steps - 1);
     return;
   }
@@ -859,8 +885,6 @@ extern "C" int bs_sim_create(const bs_model* const* models, int n_models, const 
   bs_model* model = const_cast<bs_model*>(models[0]);
   const bool contacts = !(model->d.disableflags & BS_DSBL_CONTACT) && !(model->d.disableflags & BS_DSBL_CONSTRAINT) &&
                         model->d.npair > 0;
-  if (contacts && model->d.integrator == 1)
-    return fail(BS_ERR_UNSUPPORTED, "bs_sim_create: RK4 with contacts is not implemented (use Euler or disable contacts)");
   const DeviceImage* img = nullptr;
   int rc = model_image(model, device, &img);
   if (rc) return rc;
@@ -913,7 +937,7 @@ extern "C" int bs_sim_create(const bs_model* const* models, int n_models, const 
       {&d.jar, nrow, -1}, {&d.jv, nrow, -1}, {&d.eq_coef, m.neq, -1}, {&d.fric_rf, m.nfric, -1},
       {&d.Ma, nv, -1}, {&d.grad, nv, -1}, {&d.Mgrad, nv, -1}, {&d.search, nv, -1}, {&d.Mv, nv, -1},
       {&d.H, nM, -1}, {&d.Hdinv, nv, -1},
-      {&d.rk_q0, nj, -1}, {&d.rk_v0, nv, -1}, {&d.rk_Fv, 4 * nv, -1}, {&d.rk_Fa, 4 * nv, -1},
+      {&d.rk_q0, nj, -1}, {&d.rk_v0, nv, -1}, {&d.rk_Fv, 4 * nv, -1}, {&d.rk_Fa, 4 * nv, -1}, {&d.rk_t0, 2, -1},
       {&d.pgs_W, m.solver == 0 ? nrow * nv : 0, -1}};
   size_t rows = 0;
   for (auto& sl : slots) rows += (size_t)(sl.rows > 0 ? sl.rows : 1);

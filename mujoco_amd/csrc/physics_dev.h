@@ -60,6 +60,7 @@ struct DevData {
   double *efc_D, *efc_aref, *efc_force, *jar, *jv, *eq_coef, *fric_rf;
   double *Ma, *grad, *Mgrad, *search, *Mv, *H, *Hdinv;
   double *rk_q0, *rk_v0, *rk_Fv, *rk_Fa;
+  double *rk_t0;  // [2][E]: start time of the RK4 step; 1.0 while the step is abandoned (mj_checkAcc reset)
   double *pgs_W;  // PGS only: rows of J M^-1 for the fixed rows, [(row*nv + dof)][E]
   int *solver_iter, *warning, *nefc;
 };
@@ -864,6 +865,39 @@ __device__ inline void stage_rk4(const DevModel& m, const DevData& d, long e) {
     AT(d.qpos, k) = AT(d.rk_q0, k) + h * dv;
   }
   AT(d.time, 0) = t0 + h;
+}
+
+// A13 with one launch per forward pass (needed when a forward pass spans several kernels, i.e.
+// with contacts): called after forward pass i-1, i = 1..4.  Stores F[i-1] = (qvel, qacc) and
+// moves the state to stage i (i < 4) or to the end of the step (i == 4).  mj_checkAcc is applied
+// to the first forward pass; a reset abandons the step (the next one starts from the reset state).
+__device__ inline void rk4_advance(const DevModel& m, const DevData& d, long e, int i) {
+  const long E = d.E;
+  const int nv = m.nv;
+  const double h = m.timestep;
+  const double A[3][3] = {{0.5, 0, 0}, {0, 0.5, 0}, {0, 0, 1}};
+  const double B[4] = {1 / 6., 1 / 3., 1 / 3., 1 / 6.}, C[3] = {0.5, 0.5, 1.0};
+  if (i == 1) {
+    if (env_check(m, d, e, d.qacc, nv, 2)) { AT(d.rk_t0, 1) = 1.0; return; }
+    AT(d.rk_t0, 1) = 0.0;
+    AT(d.rk_t0, 0) = AT(d.time, 0);
+    for (int k = 0; k < nv; k++) { AT(d.rk_q0, k) = AT(d.qpos, k); AT(d.rk_v0, k) = AT(d.qvel, k); }
+  }
+  if (AT(d.rk_t0, 1) != 0.0) return;
+  for (int k = 0; k < nv; k++) {
+    AT(d.rk_Fv, (i - 1) * nv + k) = AT(d.qvel, k); AT(d.rk_Fa, (i - 1) * nv + k) = AT(d.qacc, k);
+  }
+  const double t0 = AT(d.rk_t0, 0);
+  for (int k = 0; k < nv; k++) {
+    double dv = 0, da = 0;
+    if (i < 4)
+      for (int j = 0; j < i; j++) { dv += A[i - 1][j] * AT(d.rk_Fv, j * nv + k); da += A[i - 1][j] * AT(d.rk_Fa, j * nv + k); }
+    else
+      for (int j = 0; j < 4; j++) { dv += B[j] * AT(d.rk_Fv, j * nv + k); da += B[j] * AT(d.rk_Fa, j * nv + k); }
+    if (i < 4) { AT(d.qpos, k) = AT(d.rk_q0, k) + h * dv; AT(d.qvel, k) = AT(d.rk_v0, k) + h * da; }
+    else { AT(d.qvel, k) = AT(d.rk_v0, k) + h * da; AT(d.qpos, k) = AT(d.rk_q0, k) + h * dv; }
+  }
+  AT(d.time, 0) = i < 4 ? t0 + C[i - 1] * h : t0 + h;
 }
 
 // one mj_step for one environment

@@ -343,6 +343,37 @@ def test_ground_plane_contact(hand_model):
     assert err < 1e-8, err
 
 
+@pytest.mark.parametrize("kernel", ["tp", "serial"])
+def test_rk4_with_contacts(hand_model, kernel, monkeypatch):
+    """A13 with contacts: four forward passes per step, collision included in each, against the
+    oracle's RK4 (20 steps), through the tree-parallel and the serial contact kernels."""
+    import torch
+    from mujoco_amd import BatchSim, workload
+    from mujoco_amd.model import INT_RK4
+    from oracle import OracleSim
+    monkeypatch.setenv("BS_KERNEL", kernel)
+    m = _contact_model(hand_model)
+    m.opt_integrator = INT_RK4
+    E = 16
+    q, v = workload.config2_state(m, E, seed=31)
+    c = workload.config2_ctrl(m, E, seed=31)
+    sim = BatchSim(m, n_envs=E)
+    sim.data.qpos.copy_(torch.as_tensor(q)); sim.data.ctrl.copy_(torch.as_tensor(c))
+    sim.step(20); sim.sync()
+    monkeypatch.delenv("BS_KERNEL")
+    assert sim.data.warning.cpu().numpy().max() == 0
+    assert sim.data.ncon.cpu().numpy().sum() > 10
+    qg, vg, tg = sim.data.qpos.cpu().numpy(), sim.data.qvel.cpu().numpy(), sim.data.time.cpu().numpy()
+    for e in (0, 7, 15):
+        s = OracleSim(m)
+        s.qpos[:] = q[e]; s.ctrl[:] = c[e]
+        s.step(20)
+        assert np.abs(qg[e] - s.qpos).max() < 1e-8, e
+        assert np.abs(vg[e] - s.qvel).max() < 1e-6, e
+        assert abs(float(np.ravel(tg[e])[0]) - s.time) < 1e-12
+        assert sorted((g1, g2) for g1, g2, _ in sim.data.contacts(e)) == sorted((cc["geom1"], cc["geom2"]) for cc in s.contacts())
+
+
 def test_work_stealing_narrowphase(hand_model, monkeypatch):
     """BS_NARROW=ws (opt-in variant of the narrowphase) finds the same contacts as the default."""
     import torch
