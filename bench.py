@@ -44,18 +44,16 @@ def cpu_baseline(model, seconds_budget=12.0):
     """Oracle (CPU restatement, kind 'port') on this host: single thread, then all cores."""
     from mujoco_amd import workload
     from oracle import OracleSim
-    n_envs, n_steps = 64, 1000
+    n_envs, n_steps = 2048, 1000  # bounded by seconds_budget: about 12 s of single-thread work
     q, v = workload.config2_state(model, n_envs, seed=1234)
     c = workload.config2_ctrl(model, n_envs, seed=1234)
-    sims = []
-    for e in range(n_envs):
-        s = OracleSim(model)
-        s.qpos[:] = q[e]
-        s.ctrl[:] = c[e]
-        sims.append(s)
     t0 = time.perf_counter()
     done = 0
-    for s in sims:
+    s = OracleSim(model)
+    for e in range(n_envs):
+        s.reset()
+        s.qpos[:] = q[e]
+        s.ctrl[:] = c[e]
         s.step(n_steps)
         done += n_steps
         if time.perf_counter() - t0 > seconds_budget:
@@ -90,7 +88,7 @@ def _pool_worker(args):
 def cpu_baseline_allcores(model_path, contacts=False):
     import multiprocessing as mp
     cores = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16") or 16), 16)
-    n_envs, n_steps = 32, 1000
+    n_envs, n_steps = (40 if contacts else 400), 1000  # a few seconds per worker
     ctx = mp.get_context("spawn")
     t0 = time.perf_counter()
     with ctx.Pool(cores) as pool:
