@@ -114,6 +114,15 @@ int bs_sim_create(const bs_model *const *models, int n_models, const int32_t *en
                   int64_t n_envs, int device, const bs_options *opt, bs_sim **out);
 int bs_sim_destroy(bs_sim *s);
 
+/* Mixed-model batches (BASELINE.json configs[3]; no counterpart in mujoco-py, where one MjSim holds
+ * one model): with n_models > 1 the sim is a set of parts, one per model, over contiguous ranges
+ * of environments.  bs_step / bs_forward / bs_reset / bs_sync / bs_set_stream / bs_get_contacts /
+ * bs_collision_stats act on all of them; fields are addressed per part (row counts differ between
+ * models): bs_sim_part returns a borrowed handle that takes bs_get_ptr / bs_copy_field and dies
+ * with the parent.  A single-model sim has 0 parts. */
+int bs_sim_num_parts(const bs_sim *s);
+int bs_sim_part(bs_sim *s, int part, bs_sim **out_part, int64_t *env_start, int64_t *n_envs);
+
 /* Run on a caller-owned hipStream_t (e.g. PyTorch's current stream; 0 is the legacy null
  * stream) instead of the sim's own; use_own_stream != 0 switches back to the sim's stream. */
 int bs_set_stream(bs_sim *s, void *hip_stream, int use_own_stream);

@@ -11,7 +11,7 @@ from .model import Model  # noqa: F401
 def __getattr__(name):
     # BatchSim needs the native library; import lazily so the model compiler is
     # usable (and testable) without it.
-    if name in ("BatchSim", "MjSim", "MjSimState", "BatchSimError"):
+    if name in ("BatchSim", "MixedBatchSim", "MjSim", "MjSimState", "BatchSimError"):
         from . import sim
         return getattr(sim, name)
     raise AttributeError(name)

@@ -53,7 +53,7 @@ FIELD_ID = {n: i for i, n in enumerate(FIELD_NAMES)}
 # every symbol include/batchsim.h declares
 SYMBOLS = ("bs_version bs_last_error bs_device_count bs_model_create bs_model_destroy bs_sim_create "
            "bs_sim_destroy bs_set_stream bs_step bs_forward bs_reset bs_get_ptr bs_copy_field "
-           "bs_get_contacts bs_collision_stats bs_sync bs_stage_times bs_timed_steps").split()
+           "bs_get_contacts bs_collision_stats bs_sync bs_stage_times bs_timed_steps bs_sim_num_parts bs_sim_part").split()
 
 
 class BatchSimError(RuntimeError):

@@ -580,7 +580,14 @@ struct bs_sim {
   size_t derived_rows = 0;
   hipEvent_t ev[8];
   bool events = false;
+  // mixed-model batch: one child sim per model over a contiguous range of environments (each with
+  // its own arenas, since row counts differ between models); all run on this sim's stream
+  std::vector<bs_sim*> parts;
+  std::vector<int64_t> part_start;
 };
+#define NO_PARTS(s, what)                                                                             \
+  if (!(s)->parts.empty())                                                                            \
+    return fail(BS_ERR_UNSUPPORTED, what ": a mixed-model sim has one field set per model; use bs_sim_part")
 
 // kernels ----------------------------------------------------------------------------------
 #define BS_BLOCK 64
@@ -870,12 +877,39 @@ extern "C" int bs_sim_create(const bs_model* const* models, int n_models, const 
   (void)opt;
   if (!models || !out || n_models < 1 || !models[0]) return fail(BS_ERR_INVALID, "bs_sim_create: null argument");
   if (n_envs < 1) return fail(BS_ERR_INVALID, "bs_sim_create: n_envs must be >= 1 (got %lld)", (long long)n_envs);
-  if (n_models != 1)
-    return fail(BS_ERR_UNSUPPORTED, "bs_sim_create: mixed-model batches are not implemented yet (n_models=%d)",
-                n_models);
   if (env_model_id)
-    for (int64_t i = 0; i < n_envs; i++)
-      if (env_model_id[i] != 0) return fail(BS_ERR_INVALID, "bs_sim_create: env_model_id[%lld] out of range", (long long)i);
+    for (int64_t i = 0; i < n_envs; i++) {
+      if (env_model_id[i] < 0 || env_model_id[i] >= n_models)
+        return fail(BS_ERR_INVALID, "bs_sim_create: env_model_id[%lld] out of range", (long long)i);
+      if (i > 0 && env_model_id[i] < env_model_id[i - 1])
+        return fail(BS_ERR_INVALID, "bs_sim_create: env_model_id must be non-decreasing (environments sorted by model)");
+    }
+  if (n_models > 1) {
+    if (!env_model_id) return fail(BS_ERR_INVALID, "bs_sim_create: n_models > 1 needs env_model_id");
+    for (int k = 0; k < n_models; k++)
+      if (!models[k]) return fail(BS_ERR_INVALID, "bs_sim_create: models[%d] is null", k);
+    bs_sim* top = new bs_sim();
+    top->device = device; top->n_envs = n_envs;
+    int64_t i = 0;
+    for (int k = 0; k < n_models; k++) {
+      const int64_t start = i;
+      while (i < n_envs && env_model_id[i] == k) i++;
+      if (i == start) continue;  // no environment uses this model
+      bs_sim* child = nullptr;
+      const int rc = bs_sim_create(models + k, 1, nullptr, i - start, device, opt, &child);
+      if (rc) { bs_sim_destroy(top); return rc; }
+      top->parts.push_back(child);
+      top->part_start.push_back(start);
+    }
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&top->own_stream, hipStreamNonBlocking) != hipSuccess) {
+      bs_sim_destroy(top);
+      return fail(BS_ERR_HIP, "bs_sim_create: cannot create the stream of the mixed-model sim");
+    }
+    top->stream = top->own_stream;
+    for (bs_sim* c : top->parts) c->stream = top->stream;
+    *out = top;
+    return BS_OK;
+  }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
     (void)hipGetLastError();
@@ -1024,7 +1058,11 @@ extern "C" int bs_sim_create(const bs_model* const* models, int n_models, const 
 extern "C" int bs_sim_destroy(bs_sim* s) {
   if (!s) return BS_OK;
   (void)hipSetDevice(s->device);
-  (void)hipStreamSynchronize(s->stream);
+  if (s->stream) (void)hipStreamSynchronize(s->stream);
+  for (bs_sim* c : s->parts) {
+    c->stream = c->own_stream;
+    bs_sim_destroy(c);
+  }
   if (s->events)
     for (auto& ev : s->ev) (void)hipEventDestroy(ev);
   if (s->arena) (void)hipFree(s->arena);
@@ -1039,6 +1077,19 @@ extern "C" int bs_set_stream(bs_sim* s, void* hip_stream, int use_own_stream) {
   HIPCHK(hipSetDevice(s->device));
   HIPCHK(hipStreamSynchronize(s->stream));
   s->stream = use_own_stream ? s->own_stream : (hipStream_t)hip_stream;
+  for (bs_sim* c : s->parts) c->stream = s->stream;
+  return BS_OK;
+}
+
+extern "C" int bs_sim_num_parts(const bs_sim* s) { return s ? (int)s->parts.size() : 0; }
+
+extern "C" int bs_sim_part(bs_sim* s, int part, bs_sim** out, int64_t* env_start, int64_t* n_envs) {
+  if (!s || !out) return fail(BS_ERR_INVALID, "bs_sim_part: null argument");
+  if (part < 0 || part >= (int)s->parts.size())
+    return fail(BS_ERR_INVALID, "bs_sim_part: part %d out of range [0,%d)", part, (int)s->parts.size());
+  *out = s->parts[part];
+  if (env_start) *env_start = s->part_start[part];
+  if (n_envs) *n_envs = s->parts[part]->n_envs;
   return BS_OK;
 }
 
@@ -1047,6 +1098,11 @@ extern "C" int bs_step(bs_sim* s, int n_steps) {
   if (n_steps < 0) return fail(BS_ERR_INVALID, "bs_step: n_steps must be >= 0 (got %d)", n_steps);
   if (n_steps == 0) return BS_OK;
   HIPCHK(hipSetDevice(s->device));
+  if (!s->parts.empty()) {
+    for (bs_sim* c : s->parts) launch_step(c, n_steps);
+    HIPCHK(hipGetLastError());
+    return BS_OK;
+  }
   launch_step(s, n_steps);
   HIPCHK(hipGetLastError());
   return BS_OK;
@@ -1055,6 +1111,13 @@ extern "C" int bs_step(bs_sim* s, int n_steps) {
 extern "C" int bs_forward(bs_sim* s) {
   if (!s) return fail(BS_ERR_INVALID, "bs_forward: null sim");
   HIPCHK(hipSetDevice(s->device));
+  if (!s->parts.empty()) {
+    for (bs_sim* c : s->parts) {
+      const int rc = bs_forward(c);
+      if (rc) return rc;
+    }
+    return BS_OK;
+  }
   if (s->contacts)
     launch_contact_pass(s, 0, 0);
   else if (s->use_tp)
@@ -1068,6 +1131,13 @@ extern "C" int bs_forward(bs_sim* s) {
 extern "C" int bs_reset(bs_sim* s, const uint8_t* env_mask) {
   if (!s) return fail(BS_ERR_INVALID, "bs_reset: null sim");
   HIPCHK(hipSetDevice(s->device));
+  if (!s->parts.empty()) {
+    for (size_t k = 0; k < s->parts.size(); k++) {
+      const int rc = bs_reset(s->parts[k], env_mask ? env_mask + s->part_start[k] : nullptr);
+      if (rc) return rc;
+    }
+    return BS_OK;
+  }
   uint8_t* dmask = nullptr;
   if (env_mask) {
     HIPCHK(hipMalloc((void**)&dmask, (size_t)s->n_envs));
@@ -1094,6 +1164,7 @@ extern "C" int bs_get_ptr(bs_sim* s, int field_id, void** dev_ptr, int64_t shape
                           int* is_int32) {
   if (!s || !dev_ptr || !shape || !stride) return fail(BS_ERR_INVALID, "bs_get_ptr: null argument");
   if (field_id < 0 || field_id >= BS_F_COUNT) return fail(BS_ERR_INVALID, "bs_get_ptr: unknown field %d", field_id);
+  NO_PARTS(s, "bs_get_ptr");
   HIPCHK(hipSetDevice(s->device));
   if (field_id == BS_F_XMAT || field_id == BS_F_GEOM_XPOS || field_id == BS_F_GEOM_XMAT) {
     int rc = refresh_derived(s);
@@ -1111,6 +1182,7 @@ extern "C" int bs_copy_field(bs_sim* s, int field_id, void* host, int direction)
   if (!s || !host) return fail(BS_ERR_INVALID, "bs_copy_field: null argument");
   if (field_id < 0 || field_id >= BS_F_COUNT) return fail(BS_ERR_INVALID, "bs_copy_field: unknown field %d", field_id);
   if (direction != 0 && direction != 1) return fail(BS_ERR_INVALID, "bs_copy_field: direction must be 0 or 1");
+  NO_PARTS(s, "bs_copy_field");
   HIPCHK(hipSetDevice(s->device));
   const bool derived = field_id == BS_F_XMAT || field_id == BS_F_GEOM_XPOS || field_id == BS_F_GEOM_XMAT;
   if (derived) {
@@ -1135,6 +1207,9 @@ extern "C" int bs_get_contacts(bs_sim* s, int64_t env, int32_t* geom1, int32_t* 
                                int* n) {
   if (!s || !n) return fail(BS_ERR_INVALID, "bs_get_contacts: null argument");
   if (env < 0 || env >= s->n_envs) return fail(BS_ERR_INVALID, "bs_get_contacts: env %lld out of range", (long long)env);
+  for (size_t k = 0; k < s->parts.size(); k++)
+    if (env >= s->part_start[k] && env < s->part_start[k] + s->parts[k]->n_envs)
+      return bs_get_contacts(s->parts[k], env - s->part_start[k], geom1, geom2, dist, cap, n);
   *n = 0;
   if (!s->contacts) return BS_OK;
   if (cap < 0 || (cap > 0 && (!geom1 || !geom2 || !dist))) return fail(BS_ERR_INVALID, "bs_get_contacts: null output");
@@ -1161,6 +1236,12 @@ extern "C" int bs_get_contacts(bs_sim* s, int64_t env, int32_t* geom1, int32_t* 
 extern "C" int bs_collision_stats(bs_sim* s, uint64_t out[3], int reset) {
   if (!s || !out) return fail(BS_ERR_INVALID, "bs_collision_stats: null argument");
   out[0] = out[1] = out[2] = 0;
+  for (bs_sim* c : s->parts) {
+    uint64_t t[3];
+    const int rc = bs_collision_stats(c, t, reset);
+    if (rc) return rc;
+    for (int q = 0; q < 3; q++) out[q] += t[q];
+  }
   if (!s->contacts) return BS_OK;
   HIPCHK(hipSetDevice(s->device));
   HIPCHK(hipStreamSynchronize(s->stream));
@@ -1188,6 +1269,7 @@ extern "C" int bs_sync(bs_sim* s) {
 
 extern "C" int bs_stage_times(bs_sim* s, double* ms, int n) {
   if (!s || !ms || n < 5) return fail(BS_ERR_INVALID, "bs_stage_times: need room for 5 stage times");
+  NO_PARTS(s, "bs_stage_times");
   HIPCHK(hipSetDevice(s->device));
   if (s->contacts) {
     const dim3 g = dim3((unsigned)((s->n_envs + BS_BLOCK - 1) / BS_BLOCK));
@@ -1224,6 +1306,7 @@ extern "C" int bs_stage_times(bs_sim* s, double* ms, int n) {
 extern "C" int bs_timed_steps(bs_sim* s, int n_steps, double* elapsed_ms) {
   if (!s || !elapsed_ms) return fail(BS_ERR_INVALID, "bs_timed_steps: null argument");
   if (n_steps < 1) return fail(BS_ERR_INVALID, "bs_timed_steps: n_steps must be >= 1");
+  NO_PARTS(s, "bs_timed_steps");
   HIPCHK(hipSetDevice(s->device));
   HIPCHK(hipEventRecord(s->ev[5], s->stream));
   for (int k = 0; k < n_steps; k++) launch_step(s, 1);

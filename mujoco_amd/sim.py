@@ -232,3 +232,78 @@ class BatchSim:
 
 
 MjSim = BatchSim
+
+
+class _Part:
+    """Borrowed view of one model's environments inside a MixedBatchSim (dies with the parent)."""
+
+    def __init__(self, parent, index):
+        h = C.c_void_p()
+        start = C.c_int64()
+        n = C.c_int64()
+        _abi.check(_abi.lib().bs_sim_part(parent._h, int(index), C.byref(h), C.byref(start), C.byref(n)))
+        self._h = h
+        self.env_start = int(start.value)
+        self.n_envs = int(n.value)
+        self.device_id = parent.device_id
+        self.model = parent.models[parent._part_model[index]]
+        self.data = BatchData(self)
+
+
+class MixedBatchSim(BatchSim):
+    """Mixed-model batch (BASELINE.json configs[3]): environments sorted by model, one part per
+    model.  `models` is a list of compiled models, `env_model_id` a non-decreasing int array with
+    one entry per environment (or `counts`, environments per model).  step/forward/reset/sync act
+    on the whole batch; state and outputs are per part: `sim.parts[k].data.qpos` is
+    `[n_envs_k, nq_k]`, `sim.parts[k].env_start` its first environment."""
+
+    def __init__(self, models, env_model_id=None, counts=None, device_id=0, nsubsteps=1, use_torch_stream=True):
+        if (env_model_id is None) == (counts is None):
+            raise ValueError("give exactly one of env_model_id and counts")
+        if counts is not None:
+            if len(counts) != len(models):
+                raise ValueError("counts needs one entry per model")
+            env_model_id = np.repeat(np.arange(len(models)), np.asarray(counts, dtype=np.int64))
+        ids = np.ascontiguousarray(np.asarray(env_model_id, dtype=np.int32))
+        if ids.ndim != 1 or ids.size < 1:
+            raise ValueError("env_model_id must be a non-empty 1-D array")
+        if nsubsteps < 1:
+            raise ValueError("nsubsteps must be >= 1")
+        L = _abi.lib()
+        self.models = list(models)
+        self.model = None
+        self.n_envs = int(ids.size)
+        self.device_id = int(device_id)
+        self.nsubsteps = int(nsubsteps)
+        self._natives = [m if isinstance(m, NativeModel) else NativeModel(m) for m in self.models]
+        self.models = [n.model for n in self._natives]
+        arr = (C.c_void_p * len(self._natives))(*[n.handle for n in self._natives])
+        h = C.c_void_p()
+        _abi.check(L.bs_sim_create(arr, len(self._natives), ids.ctypes.data_as(C.POINTER(C.c_int32)), self.n_envs,
+                                   self.device_id, None, C.byref(h)))
+        self._h = h
+        self._part_model = [int(k) for k in sorted(set(ids.tolist()))]
+        self.parts = [_Part(self, i) for i in range(L.bs_sim_num_parts(self._h))]
+        self.data = None  # fields live in the parts
+        if use_torch_stream:
+            import torch
+            with torch.cuda.device(self.device_id):
+                st = torch.cuda.current_stream().cuda_stream
+            _abi.check(L.bs_set_stream(self._h, C.c_void_p(st), 0))
+
+    def contacts(self, env, cap=64):
+        g1 = (C.c_int32 * cap)()
+        g2 = (C.c_int32 * cap)()
+        dist = (C.c_double * cap)()
+        n = C.c_int()
+        _abi.check(_abi.lib().bs_get_contacts(self._h, int(env), g1, g2, dist, cap, C.byref(n)))
+        return [(g1[i], g2[i], dist[i]) for i in range(min(n.value, cap))]
+
+    def get_state(self):
+        return [MjSimState(p.data.time.clone(), p.data.qpos.clone(), p.data.qvel.clone(), None, {}) for p in self.parts]
+
+    def set_state(self, states):
+        for p, st in zip(self.parts, states):
+            p.data.time.copy_(st.time)
+            p.data.qpos.copy_(st.qpos)
+            p.data.qvel.copy_(st.qvel)

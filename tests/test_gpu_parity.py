@@ -459,3 +459,53 @@ def test_pgs_matches_oracle(hand_model, contacts):
     sim.step(100)
     sim.sync()
     assert np.isfinite(sim.data.qpos.cpu().numpy()).all()
+
+
+def test_mixed_model_batch(hand_model):
+    """BASELINE.json configs[3] shape: several models in one batch, environments sorted by model,
+    one bs_step for all.  Three variants of the hand (contact-free Newton, self-collision Newton,
+    contact-free PGS with heavier damping) against their own oracles."""
+    import torch
+    from mujoco_amd import MixedBatchSim, BatchSimError, workload
+    from oracle import OracleSim
+    m0 = workload.contact_free(hand_model)
+    m1 = hand_model.copy()
+    m2 = workload.contact_free(hand_model)
+    m2.opt_solver = 0
+    m2.dof_damping = m2.dof_damping * 3.0
+    models, counts = [m0, m1, m2], [70, 33, 25]
+    sim = MixedBatchSim(models, counts=counts)
+    assert len(sim.parts) == 3 and [p.n_envs for p in sim.parts] == counts
+    assert [p.env_start for p in sim.parts] == [0, 70, 103]
+    init = []
+    for k, p in enumerate(sim.parts):
+        q, v = workload.config2_state(models[k], p.n_envs, seed=50 + k)
+        c = workload.config2_ctrl(models[k], p.n_envs, seed=50 + k)
+        p.data.qpos.copy_(torch.as_tensor(q)); p.data.ctrl.copy_(torch.as_tensor(c))
+        init.append((q, c))
+    sim.step(20)
+    sim.sync()
+    for k, p in enumerate(sim.parts):
+        qg = p.data.qpos.cpu().numpy()
+        assert p.data.warning.cpu().numpy().max() == 0
+        for e in (0, p.n_envs - 1):
+            s = OracleSim(models[k])
+            s.qpos[:] = init[k][0][e]; s.ctrl[:] = init[k][1][e]
+            s.step(20)
+            assert np.abs(qg[e] - s.qpos).max() < 1e-8, (k, e)
+            if k == 1:
+                got = sorted((g1, g2) for g1, g2, _ in sim.contacts(p.env_start + e))
+                assert got == sorted((cc["geom1"], cc["geom2"]) for cc in s.contacts())
+    assert sim.collision_stats()["contacts"] > 0
+    # masked reset addresses environments of the whole batch
+    mask = np.zeros(sim.n_envs, dtype=np.uint8)
+    mask[71] = 1
+    sim.reset(mask)
+    sim.sync()
+    assert np.abs(sim.parts[1].data.qpos.cpu().numpy()[1] - m1.qpos0).max() == 0
+    assert np.abs(sim.parts[1].data.qpos.cpu().numpy()[0] - m1.qpos0).max() > 0
+    with pytest.raises(BatchSimError):
+        sim.stage_times()
+    with pytest.raises(BatchSimError):
+        MixedBatchSim(models, env_model_id=[0, 2, 1])
+    sim.close()
