@@ -101,6 +101,67 @@ def cpu_baseline_allcores(model_path, contacts=False):
                        f"pool wall {wall:.1f} s incl. spawn)")
 
 
+def main_mixed(args):
+    """BASELINE.json configs[3]: the three exported hands (tests/golden/*.npz, compiled from the
+    reference's fusion_export_* folders by the exporter restatement, see make_golden.py for the
+    declared mesh stand-ins) in one mixed-model batch, environments split evenly and sorted by
+    model, once with Newton and once with PGS.  Not the default bench line."""
+    import torch
+    from mujoco_amd import MixedBatchSim, Model, workload
+    from mujoco_amd.model import SOL_NEWTON, SOL_PGS
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the product path")
+    names = ["dexterous_model.npz", "hand_1120.npz", "hand_1206.npz"]
+    base = [Model.load(os.path.join(ROOT, "tests", "golden", n)) for n in names]
+    if not args.contacts:
+        base = [workload.contact_free(m) for m in base]
+    per = args.envs // 3
+    res = {}
+    for label, sol in (("newton", SOL_NEWTON), ("pgs", SOL_PGS)):
+        models = []
+        for m in base:
+            m = m.copy()
+            m.opt_solver = sol
+            models.append(m)
+        sim = MixedBatchSim(models, counts=[per] * 3)
+        banks = []
+        for k, p in enumerate(sim.parts):
+            q, v = workload.config2_state(models[k], per, seed=1234 + k)
+            p.data.qpos.copy_(torch.as_tensor(q))
+            banks.append(torch.as_tensor(np.stack([workload.config2_ctrl(models[k], per, seed=1234 + k, resample_idx=i)
+                                                   for i in range(4)])).to(p.data.ctrl.device))
+
+        def run(n, period):
+            done = 0
+            while done < n:
+                for k, p in enumerate(sim.parts):
+                    p.data.ctrl.copy_(banks[k][period % 4])
+                sim.step(min(CTRL_PERIOD, n - done))
+                done += CTRL_PERIOD
+                period += 1
+            return period
+
+        period = run(args.warmup, 0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(args.steps, period)
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        res[label] = {"value": 3 * per * args.steps / wall, "ms_per_step": wall * 1e3 / args.steps,
+                      "mean_solver_iter": [float(p.data.solver_iter.double().mean().item()) for p in sim.parts],
+                      "envs_with_warnings": int(sum((p.data.warning != 0).sum().item() for p in sim.parts))}
+        sim.close()
+    out = {"metric": "env-steps/sec", "value": res["newton"]["value"], "unit": "env-steps/s", "n_gpus": 1,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["newton"]["ms_per_step"],
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": "BASELINE.json configs[3]: three exported hands (24/23/24 bodies, 21/20/21 dofs) in one "
+                                  "mixed-model batch, " + ("mesh self-collision on" if args.contacts else "joint-space only")
+                                  + ", random ctrl resampled every 50 steps, Euler, Newton (value) and PGS",
+                      "n_envs_per_model": per, "n_envs_total": 3 * per, "models": names},
+           "newton": res["newton"], "pgs": res["pgs"]}
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -111,7 +172,12 @@ def main():
     ap.add_argument("--contacts", action="store_true",
                     help="BASELINE.json configs[2] shape instead of configs[1]: mesh self-collision enabled "
                          "(use with --envs 65536); not the default bench line")
+    ap.add_argument("--mixed", action="store_true",
+                    help="BASELINE.json configs[3]: three hands in one mixed-model batch, Newton and PGS; "
+                         "not the default bench line")
     args = ap.parse_args()
+    if args.mixed:
+        return main_mixed(args)
 
     import torch
     from mujoco_amd import BatchSim, Model, workload

@@ -509,3 +509,33 @@ def test_mixed_model_batch(hand_model):
     with pytest.raises(BatchSimError):
         MixedBatchSim(models, env_model_id=[0, 2, 1])
     sim.close()
+
+
+def test_three_exported_hands_in_one_batch():
+    """BASELINE.json configs[3] with the real models: the exporter restatement's three hands
+    (tests/golden/*.npz) stepped in one mixed batch, self-collision on, against their oracles."""
+    import os
+    import torch
+    from mujoco_amd import MixedBatchSim, Model, workload
+    from oracle import OracleSim
+    g = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    models = [Model.load(os.path.join(g, n)) for n in ("dexterous_model.npz", "hand_1120.npz", "hand_1206.npz")]
+    sim = MixedBatchSim(models, counts=[6, 6, 6])
+    init = []
+    for k, p in enumerate(sim.parts):
+        q, v = workload.config2_state(models[k], p.n_envs, seed=70 + k)
+        c = workload.config2_ctrl(models[k], p.n_envs, seed=70 + k)
+        p.data.qpos.copy_(torch.as_tensor(q)); p.data.ctrl.copy_(torch.as_tensor(c))
+        init.append((q, c))
+    sim.step(10)
+    sim.sync()
+    for k, p in enumerate(sim.parts):
+        qg, ag = p.data.qpos.cpu().numpy(), p.data.qacc.cpu().numpy()
+        for e in (0, 5):
+            s = OracleSim(models[k])
+            s.qpos[:] = init[k][0][e]; s.ctrl[:] = init[k][1][e]
+            s.step(10)
+            assert np.abs(qg[e] - s.qpos).max() < 1e-9, (k, e)
+            assert np.abs(ag[e] - s.qacc).max() / max(1.0, np.abs(s.qacc).max()) < 1e-7, (k, e)
+            assert sorted((a, b) for a, b, _ in sim.contacts(p.env_start + e)) == sorted((cc["geom1"], cc["geom2"]) for cc in s.contacts())
+    sim.close()
