@@ -539,3 +539,42 @@ def test_three_exported_hands_in_one_batch():
             assert np.abs(ag[e] - s.qacc).max() / max(1.0, np.abs(s.qacc).max()) < 1e-7, (k, e)
             assert sorted((a, b) for a, b, _ in sim.contacts(p.env_start + e)) == sorted((cc["geom1"], cc["geom2"]) for cc in s.contacts())
     sim.close()
+
+
+def test_vec_env_rollout(hand_model):
+    """RL glue: observation / reward definitions, frame skip, device-side
+    auto-reset; the physics under it is the same bs_step as everywhere else."""
+    import torch
+    from mujoco_amd import BatchSim, workload
+    from mujoco_amd.env import HandVecEnv
+    from oracle import OracleSim
+    m = workload.contact_free(hand_model)
+    E = 32
+    sim = BatchSim(m, n_envs=E)
+    env = HandVecEnv(sim, frame_skip=10, episode_steps=3)
+    obs = env.reset()
+    assert obs.shape == (E, m.nq + m.nv) and obs.dtype == torch.float32
+    assert torch.equal(obs[:, :m.nq].double(), torch.as_tensor(m.qpos0).to(obs.device).expand(E, -1).double().float().double())
+    g = torch.Generator(device=obs.device); g.manual_seed(3)
+    lo, hi = env.ctrl_lo, env.ctrl_hi
+    act = lo + (hi - lo) * torch.rand((E, m.nu), generator=g, device=obs.device, dtype=torch.float64)
+    o1, r1, d1, info = env.step(act * 3.0 - 1.0)  # out-of-range parts are clamped like MuJoCo clamps ctrl
+    clamped = torch.minimum(torch.maximum(act * 3.0 - 1.0, lo), hi)
+    s = OracleSim(m)
+    s.ctrl[:] = clamped[5].cpu().numpy()
+    s.step(10)
+    assert np.abs(o1[5, :m.nq].cpu().numpy() - s.qpos).max() < 1e-6
+    want_r = -float(((s.qpos[m.actuator_trnid] - s.ctrl) ** 2).sum())
+    assert abs(float(r1[5]) - want_r) < 1e-5 * max(1.0, abs(want_r))
+    assert not bool(d1.any())
+    env.step(act)
+    o3, r3, d3, info = env.step(act)
+    assert bool(d3.all())  # episode_steps = 3
+    assert torch.equal(o3[:, :m.nq].double(), obs[:, :m.nq].double()) and float(o3[:, m.nq:].abs().max()) == 0.0
+    assert float(info["terminal_obs"][:, m.nq:].abs().max()) > 0
+    assert float(sim.data.time.max()) == 0.0 and int(env.t.max()) == 0
+    # a NaN in one environment: mj_check* resets it, the env reports done for that one only
+    sim.data.qvel[7, 2] = float("nan")
+    o4, r4, d4, info = env.step(act)
+    assert bool(d4[7]) and int(d4.sum()) == 1 and bool(info["failed"][7])
+    assert int(sim.data.warning.abs().max()) == 0
