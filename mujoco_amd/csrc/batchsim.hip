@@ -582,6 +582,11 @@ struct bs_sim {
   bool events = false;
   // mixed-model batch: one child sim per model over a contiguous range of environments (each with
   // its own arenas, since row counts differ between models); all run on this sim's stream
+  // two halves of a contact batch on two streams: kernels of different kinds overlap (both the
+  // narrowphase and k_tpc leave the SIMDs half idle on their own)
+  hipStream_t aux_stream[3] = {nullptr, nullptr, nullptr};
+  hipEvent_t fork_ev = nullptr, join_ev[3] = {nullptr, nullptr, nullptr};
+  int split = 1;  // number of ranges (1 = no split)
   std::vector<bs_sim*> parts;
   std::vector<int64_t> part_start;
 };
@@ -737,7 +742,7 @@ __global__ __launch_bounds__(64) void k_c_broad(ColModel cm, DevData d, ColData 
 #define NB_THREADS 256
 __global__ __launch_bounds__(NB_THREADS) void k_c_narrow_flat(ColModel cm, DevData d, ColData c) {
   __shared__ int pre[NB_ENVS + 1];
-  const long e0 = (long)blockIdx.x * NB_ENVS;
+  const long e0 = d.env0 + (long)blockIdx.x * NB_ENVS;
   const int tid = threadIdx.x;
   if (tid < NB_ENVS) {  // first wavefront: inclusive scan of the candidate counts with DPP-free shuffles
     const long e = e0 + tid, E = d.E;
@@ -776,7 +781,7 @@ __global__ __launch_bounds__(NB_THREADS) void k_c_narrow_flat(ColModel cm, DevDa
 __global__ __launch_bounds__(NW_THREADS) void k_c_narrow_ws(ColModel cm, DevData d, ColData c) {
   __shared__ int pre[NB_ENVS + 1];
   __shared__ int next;
-  const long e0 = (long)blockIdx.x * NB_ENVS;
+  const long e0 = d.env0 + (long)blockIdx.x * NB_ENVS;
   const int tid = threadIdx.x;
   if (tid < NB_ENVS) {
     const long e = e0 + tid, E = d.E;
@@ -820,33 +825,36 @@ static inline dim3 grid_for(const bs_sim* s) { return dim3((unsigned)((s->n_envs
 static inline dim3 grid_tp(const bs_sim* s) { return dim3((unsigned)((s->n_envs + 1) / 2)); }
 // narrowphase: flattened work items by default; BS_NARROW=ws selects the work-stealing variant
 // (measured slower on MI355X at 65536 envs: 2.6 ms vs 1.9 ms)
-static void launch_narrow(bs_sim* s) {
-  const dim3 g((unsigned)((s->n_envs + NB_ENVS - 1) / NB_ENVS));
+static void launch_narrow(bs_sim* s, const DevData& dd, hipStream_t st) {
+  const dim3 g((unsigned)((dd.n_envs - dd.env0 + NB_ENVS - 1) / NB_ENVS));
   if (s->narrow_ws)
-    hipLaunchKernelGGL(k_c_narrow_ws, g, dim3(NW_THREADS), 0, s->stream, s->cm, s->dd, s->cd);
+    hipLaunchKernelGGL(k_c_narrow_ws, g, dim3(NW_THREADS), 0, st, s->cm, dd, s->cd);
   else
-    hipLaunchKernelGGL(k_c_narrow_flat, g, dim3(NB_THREADS), 0, s->stream, s->cm, s->dd, s->cd);
+    hipLaunchKernelGGL(k_c_narrow_flat, g, dim3(NB_THREADS), 0, st, s->cm, dd, s->cd);
+}
+// one forward pass (mode 1) or step (mode 0) with contacts through the tree-parallel kernels, for
+// the environments [dd.env0, dd.n_envs) on stream st
+static void launch_tpc_pass(bs_sim* s, const DevData& dd, hipStream_t st, int mode, int dump) {
+  const dim3 g((unsigned)((dd.n_envs - dd.env0 + 1) / 2));
+  const size_t lds_col = (size_t)2 * s->cm.ngeom * TPG_SLOT * sizeof(double);
+  hipLaunchKernelGGL(k_tp_col, g, dim3(64), lds_col, st, s->dm, s->tp, dd, s->cm, s->cd);
+  launch_narrow(s, dd, st);
+  const int ntri = s->dm.nbody * (s->dm.nbody + 1) / 2;
+  const size_t lds = (size_t)(2 * ntri + 2 * TP_LPE * TPC_SLOT + 2 * TP_LPE * 3) * sizeof(double);
+  hipLaunchKernelGGL(k_tpc, g, dim3(64), lds, st, s->dm, s->tp, dd, s->cm, s->cd, mode, dump);
 }
 // check: mj_checkPos/Vel first; integrate: mj_step (Euler) rather than mj_forward; fast: let the
 // tree-parallel kernels run a forward pass too (they leave the position-stage intermediates of
 // bs_forward unwritten, which the RK4 stages do not need)
 static void launch_contact_pass(bs_sim* s, int check, int integrate, int dump = 1, int fast = 0) {
-  const dim3 g = dim3((unsigned)((s->n_envs + BS_BLOCK - 1) / BS_BLOCK));
-  const bool tp = s->use_tpc && (integrate || fast);
-  if (tp) {
-    const size_t lds = (size_t)2 * s->cm.ngeom * TPG_SLOT * sizeof(double);
-    hipLaunchKernelGGL(k_tp_col, grid_tp(s), dim3(64), lds, s->stream, s->dm, s->tp, s->dd, s->cm, s->cd);
-  } else {
-    hipLaunchKernelGGL(k_c_pos, g, dim3(BS_BLOCK), 0, s->stream, s->dm, s->dd, s->cd, check);
-    hipLaunchKernelGGL(k_c_broad, dim3((unsigned)s->n_envs), dim3(64), 0, s->stream, s->cm, s->dd, s->cd);
-  }
-  launch_narrow(s);
-  if (tp) {
-    const int ntri = s->dm.nbody * (s->dm.nbody + 1) / 2;
-    const size_t lds = (size_t)(2 * ntri + 2 * TP_LPE * TPC_SLOT + 2 * TP_LPE * 3) * sizeof(double);
-    hipLaunchKernelGGL(k_tpc, grid_tp(s), dim3(64), lds, s->stream, s->dm, s->tp, s->dd, s->cm, s->cd, integrate ? 0 : 1, dump);
+  if (s->use_tpc && (integrate || fast)) {
+    launch_tpc_pass(s, s->dd, s->stream, integrate ? 0 : 1, dump);
     return;
   }
+  const dim3 g = dim3((unsigned)((s->n_envs + BS_BLOCK - 1) / BS_BLOCK));
+  hipLaunchKernelGGL(k_c_pos, g, dim3(BS_BLOCK), 0, s->stream, s->dm, s->dd, s->cd, check);
+  hipLaunchKernelGGL(k_c_broad, dim3((unsigned)s->n_envs), dim3(64), 0, s->stream, s->cm, s->dd, s->cd);
+  launch_narrow(s, s->dd, s->stream);
   hipLaunchKernelGGL(k_c_dyn, g, dim3(BS_BLOCK), s->hs_bytes, s->stream, s->dm, s->cm, s->dd, s->cd, s->kd, integrate,
                      s->hs_bytes ? 1 : 0);
 }
@@ -860,6 +868,27 @@ static void launch_step(bs_sim* s, int n_steps) {
           launch_contact_pass(s, 0, 0, i == 4 && k == n_steps - 1, 1);
           hipLaunchKernelGGL(k_rk4_advance, grid_for(s), dim3(BS_BLOCK), 0, s->stream, s->dm, s->dd, i);
         }
+      return;
+    }
+    if (s->use_tpc && s->split > 1) {
+      // range 0 on the sim's stream, the others on auxiliary streams, joined at the end
+      const int np = s->split;
+      DevData part[4];
+      const long chunk = (s->n_envs / np + 63) / 64 * 64;
+      for (int q = 0; q < np; q++) {
+        part[q] = s->dd;
+        part[q].env0 = q * chunk;
+        part[q].n_envs = q == np - 1 ? s->n_envs : (q + 1) * chunk;
+      }
+      (void)hipEventRecord(s->fork_ev, s->stream);
+      for (int q = 1; q < np; q++) (void)hipStreamWaitEvent(s->aux_stream[q - 1], s->fork_ev, 0);
+      for (int k = 0; k < n_steps; k++)
+        for (int q = 0; q < np; q++)
+          launch_tpc_pass(s, part[q], q == 0 ? s->stream : s->aux_stream[q - 1], 0, k == n_steps - 1);
+      for (int q = 1; q < np; q++) {
+        (void)hipEventRecord(s->join_ev[q - 1], s->aux_stream[q - 1]);
+        (void)hipStreamWaitEvent(s->stream, s->join_ev[q - 1], 0);
+      }
       return;
     }
     for (int k = 0; k < n_steps; k++) launch_contact_pass(s, 1, 1, k == n_steps - 1);
@@ -1048,6 +1077,19 @@ extern "C" int bs_sim_create(const bs_model* const* models, int n_models, const 
   }
   for (auto& ev : s->ev) HIPCHK(hipEventCreate(&ev));
   s->events = true;
+  {
+    const char* sp = getenv("BS_SPLIT");  // ranges of a contact batch run on separate streams
+    int np = sp ? atoi(sp) : (n_envs >= 16384 ? 2 : 1);
+    np = np < 1 ? 1 : (np > 4 ? 4 : np);
+    s->split = s->use_tpc && n_envs >= 128 * np ? np : 1;
+    if (s->split > 1) {
+      HIPCHK(hipEventCreateWithFlags(&s->fork_ev, hipEventDisableTiming));
+      for (int q = 0; q < s->split - 1; q++) {
+        HIPCHK(hipStreamCreateWithFlags(&s->aux_stream[q], hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&s->join_ev[q], hipEventDisableTiming));
+      }
+    }
+  }
   hipLaunchKernelGGL(k_reset, grid_for(s), dim3(BS_BLOCK), 0, s->stream, s->dm, s->dd, (const uint8_t*)nullptr);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(s->stream));
@@ -1065,6 +1107,13 @@ extern "C" int bs_sim_destroy(bs_sim* s) {
   }
   if (s->events)
     for (auto& ev : s->ev) (void)hipEventDestroy(ev);
+  for (int q = 0; q < 3; q++)
+    if (s->aux_stream[q]) {
+      (void)hipStreamSynchronize(s->aux_stream[q]);
+      (void)hipStreamDestroy(s->aux_stream[q]);
+      (void)hipEventDestroy(s->join_ev[q]);
+    }
+  if (s->fork_ev) (void)hipEventDestroy(s->fork_ev);
   if (s->arena) (void)hipFree(s->arena);
   if (s->carena) (void)hipFree(s->carena);
   if (s->own_stream) (void)hipStreamDestroy(s->own_stream);
@@ -1277,7 +1326,7 @@ extern "C" int bs_stage_times(bs_sim* s, double* ms, int n) {
     hipLaunchKernelGGL(k_c_pos, g, dim3(BS_BLOCK), 0, s->stream, s->dm, s->dd, s->cd, 1);
     HIPCHK(hipEventRecord(s->ev[1], s->stream));
     hipLaunchKernelGGL(k_c_broad, dim3((unsigned)s->n_envs), dim3(64), 0, s->stream, s->cm, s->dd, s->cd);
-    launch_narrow(s);
+    launch_narrow(s, s->dd, s->stream);
     HIPCHK(hipEventRecord(s->ev[2], s->stream));
     hipLaunchKernelGGL(k_c_dyn, g, dim3(BS_BLOCK), s->hs_bytes, s->stream, s->dm, s->cm, s->dd, s->cd, s->kd, 1,
                        s->hs_bytes ? 1 : 0);

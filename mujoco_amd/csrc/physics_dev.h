@@ -51,7 +51,8 @@ struct DevModel {
 
 struct DevData {
   long E;  // padded environment count = row stride
-  long n_envs;
+  long n_envs;  // end of the environment range a launch covers
+  long env0;    // its start (tree-parallel contact kernels only: two halves of a batch on two streams)
   double *qpos, *qvel, *ctrl, *qfrc_applied, *qacc, *qacc_warmstart, *time;
   double *xpos, *xquat, *xipos, *xanchor, *xaxis, *rootcom, *cinert, *crb, *cdof, *qM, *qLD,
       *qLDiagInv;

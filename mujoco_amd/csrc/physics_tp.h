@@ -425,7 +425,7 @@ __device__ __forceinline__ void tp_collide_prep(const DevModel& m, const TpModel
                                                 const ColModel& cm, const ColData& cd, double* gfr) {
   const int tid = threadIdx.x;
   const int l = tid & (TP_LPE - 1), base = tid & ~(TP_LPE - 1);
-  long env = (long)blockIdx.x * (64 / TP_LPE) + (tid / TP_LPE);
+  long env = d.env0 + (long)blockIdx.x * (64 / TP_LPE) + (tid / TP_LPE);
   const bool env_ok = env < d.n_envs;
   if (!env_ok) env = d.n_envs - 1;
   const long E = d.E, e = env;
@@ -566,7 +566,7 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
   for (int f = 0; f < 2 * TP_MAXC; f++) tbl[f * 64 + tid] = lane_ref(TPI_BCHILD + f);
   tbl[TPL_ANCMASK * 64 + tid] = t.lane[TPI_ANCMASK * TP_LPE + l];
   __syncthreads();
-  long env = (long)blockIdx.x * (64 / TP_LPE) + (tid / TP_LPE);
+  long env = d.env0 + (long)blockIdx.x * (64 / TP_LPE) + (tid / TP_LPE);
   const bool env_ok = env < d.n_envs;
   if (!env_ok) env = d.n_envs - 1;
   const long E = d.E, e = env;

@@ -374,6 +374,30 @@ def test_rk4_with_contacts(hand_model, kernel, monkeypatch):
         assert sorted((g1, g2) for g1, g2, _ in sim.data.contacts(e)) == sorted((cc["geom1"], cc["geom2"]) for cc in s.contacts())
 
 
+def test_two_stream_split_is_bitwise_neutral(hand_model, monkeypatch):
+    """BS_SPLIT=n runs ranges of a contact batch on separate streams (overlap of the narrowphase with
+    the dynamics kernel); it must not change a single bit of the result."""
+    import torch
+    from mujoco_amd import BatchSim, workload
+    m = _contact_model(hand_model)
+    E = 389
+    q, v = workload.config2_state(m, E, seed=123)
+    c = workload.config2_ctrl(m, E, seed=123)
+    res = {}
+    for split in ("1", "2", "3"):
+        monkeypatch.setenv("BS_SPLIT", split)
+        sim = BatchSim(m, n_envs=E)
+        sim.data.qpos.copy_(torch.as_tensor(q)); sim.data.ctrl.copy_(torch.as_tensor(c))
+        sim.step(5); sim.sync()
+        res[split] = [getattr(sim.data, k).cpu().numpy().copy() for k in ("qpos", "qvel", "qacc", "ncon", "xpos", "time")]
+        del sim
+    monkeypatch.delenv("BS_SPLIT")
+    assert res["1"][3].sum() > 300
+    for split in ("2", "3"):
+        for a, b in zip(res["1"], res[split]):
+            assert np.array_equal(a, b)
+
+
 def test_work_stealing_narrowphase(hand_model, monkeypatch):
     """BS_NARROW=ws (opt-in variant of the narrowphase) finds the same contacts as the default."""
     import torch
