@@ -85,7 +85,7 @@ static void build_tp(bs_model* m) {
   m->tp_ok = 0;
   memset(&m->tp, 0, sizeof m->tp);
   auto no = [&](const char* why) { m->tp_why = why; };
-  if (nb > TP_LPE) return no("more than 32 bodies");
+  if (nb > TP_LPE - 1) return no("more than 31 bodies (lane 31 of an environment must stay empty)");
   std::vector<int> depth(nb, 0), dd(nv, 1), jnt_of(nb, -1), act_of(nv, -1);
   for (int b = 1; b < nb; b++) {
     depth[b] = depth[s.body_parentid[b]] + 1;

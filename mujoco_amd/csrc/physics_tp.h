@@ -9,7 +9,7 @@
 // for the exported hands) instead of body by body.
 //
 // Eligibility (checked on the host, otherwise the serial kernel in physics_dev.h is used):
-// nbody <= 32, at most one hinge/slide joint per body, dof depth <= TP_MAXD, every joint
+// nbody <= 31 (lane 31 stays empty: the all-zero lane), at most one hinge/slide joint per body, dof depth <= TP_MAXD, every joint
 // equality couples a dof (joint1) with one of its ancestors (joint2), a dof owns / is referenced
 // by at most one equality, at most one actuator per joint, contacts disabled.
 //
@@ -115,6 +115,8 @@ struct TpFac { TpRow R; double dinv; };
 // what the dof-tree helpers need about this lane (passed by value, lives in registers)
 struct TpCtx {
   int self_sa;           // own bpermute address
+  int zero_sa;           // address of a lane beyond nbody: everything it holds is zero, so a lane that has
+                         // nothing to receive reads from there and adds unconditionally (no per-value select)
   int anc_sa[TP_MAXD];   // address of the a-th ancestor dof's lane (own address if none)
   int dd;                // entries in this dof's row (0 = no dof on this lane)
   int maxdd;
@@ -155,8 +157,7 @@ __device__ TP_HELPER_ATTR TpFac tp_factor(TpCtx c, TpRow Rin) {
     const bool par = c.dd == D - 1;
     for (int ch = 0; ch < c.nchild[D]; ch++) {
       const int src = c.tbl[(TPL_DCHILD + ch) * 64 + threadIdx.x];
-      const bool take = par && src >= 0;
-      const int sa = src >= 0 ? src : c.self_sa;
+      const int sa = par && src >= 0 ? src : c.zero_sa;
 #pragma unroll
       for (int a = 1; a < TP_MAXD; a++) {
         if (a >= D) continue;
@@ -164,10 +165,8 @@ __device__ TP_HELPER_ATTR TpFac tp_factor(TpCtx c, TpRow Rin) {
         for (int b = a; b < TP_MAXD; b++) {
           if (b >= D) continue;
           const double v = bperm(T[pair_idx(a, b)], sa);
-          if (take) {
-            if (a == 1) R[b - 1] -= v;
-            else A[pair_idx(a - 1, b - 1)] += v;
-          }
+          if (a == 1) R[b - 1] -= v;
+          else A[pair_idx(a - 1, b - 1)] += v;
         }
       }
     }
@@ -195,16 +194,13 @@ __device__ TP_HELPER_ATTR double tp_solve(TpCtx c, TpRow Rin, double dinv, doubl
       if (a < D) T[a] = is ? R[a] * x + W[a] : 0.0;
     for (int ch = 0; ch < c.nchild[D]; ch++) {
       const int src = c.tbl[(TPL_DCHILD + ch) * 64 + threadIdx.x];
-      const bool take = par && src >= 0;
-      const int sa = src >= 0 ? src : c.self_sa;
+      const int sa = par && src >= 0 ? src : c.zero_sa;
 #pragma unroll
       for (int a = 1; a < TP_MAXD; a++) {
         if (a >= D) continue;
         const double v = bperm(T[a], sa);
-        if (take) {
-          if (a == 1) x -= v;
-          else W[a - 1] += v;
-        }
+        if (a == 1) x -= v;
+        else W[a - 1] += v;
       }
     }
   }
@@ -246,16 +242,13 @@ __device__ TP_HELPER_ATTR double tp_mul_m(TpCtx c, TpRow Min, double v) {
       if (a < D) T[a] = is ? Mr[a] * v + W[a] : 0.0;
     for (int ch = 0; ch < c.nchild[D]; ch++) {
       const int src = c.tbl[(TPL_DCHILD + ch) * 64 + threadIdx.x];
-      const bool take = par && src >= 0;
-      const int sa = src >= 0 ? src : c.self_sa;
+      const int sa = par && src >= 0 ? src : c.zero_sa;
 #pragma unroll
       for (int a = 1; a < TP_MAXD; a++) {
         if (a >= D) continue;
         const double x = bperm(T[a], sa);
-        if (take) {
-          if (a == 1) res += x;
-          else W[a - 1] += x;
-        }
+        if (a == 1) res += x;
+        else W[a - 1] += x;
       }
     }
   }
@@ -582,7 +575,7 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
   const bool isb = l < m.nbody && l > 0;
   const int b = l < m.nbody ? l : 0, j = has_dof ? jnt : 0;
   TpCtx c;
-  c.self_sa = self_sa; c.dd = has_dof ? t.lane[TPI_DD * TP_LPE + l] : 0; c.maxdd = t.maxdd; c.tbl = (tp_lds_ptr)tbl;
+  c.self_sa = self_sa; c.zero_sa = (base + TP_LPE - 1) * 4; c.dd = has_dof ? t.lane[TPI_DD * TP_LPE + l] : 0; c.maxdd = t.maxdd; c.tbl = (tp_lds_ptr)tbl;
 #pragma unroll
   for (int a = 0; a < TP_MAXD; a++) {
     const int v = lane_ref(TPI_ANC + a);
@@ -755,13 +748,9 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
           const bool par = isb && depth == lvl - 1;
           for (int ch = 0; ch < t.lvl_bchild[lvl]; ch++) {
             const int src = tbl[(TPL_BCHILD + ch) * 64 + tid];
-            const bool take = par && src >= 0;
-            const int sa = src >= 0 ? src : self_sa;
+            const int sa = par && src >= 0 ? src : c.zero_sa;
 #pragma unroll
-            for (int k = 0; k < 10; k++) {
-              const double v = bperm(crb[k], sa);
-              if (take) crb[k] += v;
-            }
+            for (int k = 0; k < 10; k++) crb[k] += bperm(crb[k], sa);
           }
         }
         double buf[6];
@@ -814,13 +803,9 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
           const bool par = isb && depth == lvl - 1;
           for (int ch = 0; ch < t.lvl_bchild[lvl]; ch++) {
             const int src = tbl[(TPL_BCHILD + ch) * 64 + tid];
-            const bool take = par && src >= 0;
-            const int sa = src >= 0 ? src : self_sa;
+            const int sa = par && src >= 0 ? src : c.zero_sa;
 #pragma unroll
-            for (int k = 0; k < 6; k++) {
-              const double x = bperm(f[k], sa);
-              if (take) f[k] += x;
-            }
+            for (int k = 0; k < 6; k++) f[k] += bperm(f[k], sa);
           }
         }
         double s = 0;
