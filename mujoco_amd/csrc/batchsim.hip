@@ -739,9 +739,10 @@ __global__ __launch_bounds__(64) void k_c_broad(ColModel cm, DevData d, ColData 
 // an exclusive scan of the candidate counts in LDS, then every lane takes items round-robin, so
 // no lane idles on environments with few candidates and no wavefront is launched for empty slots
 #define NB_ENVS 64
-#define NB_THREADS 256
+#define NB_THREADS 128
 __global__ __launch_bounds__(NB_THREADS) void k_c_narrow_flat(ColModel cm, DevData d, ColData c) {
   __shared__ int pre[NB_ENVS + 1];
+  __shared__ MprState mpr[NB_THREADS];  // MPR state of every lane (see mpr_penetration)
   const long e0 = d.env0 + (long)blockIdx.x * NB_ENVS;
   const int tid = threadIdx.x;
   if (tid < NB_ENVS) {  // first wavefront: inclusive scan of the candidate counts with DPP-free shuffles
@@ -764,7 +765,7 @@ __global__ __launch_bounds__(NB_THREADS) void k_c_narrow_flat(ColModel cm, DevDa
       if (pre[mid] <= item) lo = mid;
       else hi = mid;
     }
-    col_narrowphase(cm, d, c, e0 + lo, item - pre[lo], acc);
+    col_narrowphase(cm, d, c, e0 + lo, item - pre[lo], acc, mpr[tid]);
   }
   if (c.stat) {  // work counters: wavefront reduction, then one atomic each
     for (int off = 32; off > 0; off >>= 1) {

@@ -204,6 +204,12 @@ __device__ inline double origin_tri_dist2(const V3& a, const V3& b, const V3& c,
 // portal, refine until the portal encloses the origin ray, push the portal to the surface) are the
 // values of `state`; the caller owns the loop around the support call, so the lanes of a
 // wavefront stay converged on the expensive part whatever phase each one is in.
+__device__ __forceinline__ void swap3(V3& a, V3& b) {
+  const double x = a.x, y = a.y, z = a.z;
+  a.x = b.x; a.y = b.y; a.z = b.z;
+  b.x = x; b.y = y; b.z = z;
+}
+__device__ __forceinline__ void swap_spt(Spt& a, Spt& b) { swap3(a.v, b.v); swap3(a.v1, b.v1); swap3(a.v2, b.v2); }
 struct MprState {
   Spt P[4];
   V3 d;           // direction of the next support query
@@ -248,7 +254,7 @@ __device__ __forceinline__ int mpr_step(MprState& M, const Spt& s, double tol, i
     if (c_is_zero(dt) || dt < 0) return 2;
     d = normalized(cross(sub(P[1].v, P[0].v), sub(P[2].v, P[0].v)));
     if (dot(d, P[0].v) > 0) {
-      const Spt t = P[1]; P[1] = P[2]; P[2] = t;
+      swap_spt(P[1], P[2]);
       d = neg(d);
     }
     guard = 1;
@@ -323,9 +329,11 @@ __device__ __forceinline__ int mpr_step(MprState& M, const Spt& s, double tol, i
   return 0;
 }
 // returns true when the inflated hulls intersect; fills depth, dir (unit, obj1 -> obj2), pos
+// `Mp`: where the state lives.  The portal update copies structs through selected pointers, so the
+// state is a memory object whatever one does; the kernels hand in a slot of LDS (one per lane,
+// 81-dword stride: conflict-free), which costs a fraction of the scratch-memory round trips.
 __device__ inline bool mpr_penetration(CObj& a, CObj& b, double tol, int maxit, double& depth, V3& dir, V3& pos,
-                                       int& iters) {
-  MprState M;
+                                       int& iters, MprState& M) {
   mpr_begin(M, a.xpos, b.xpos);
   for (;;) {
     const Spt s = md_support(a, b, M.d);
@@ -438,7 +446,7 @@ __device__ inline void col_broadphase(const ColModel& cm, const DevData& d, cons
 // `acc` (optional): per-lane work counters {pairs, MPR support iterations}; the kernel reduces them
 // over the wavefront before touching ColData::stat (one atomic per wavefront, not per pair)
 __device__ inline void col_narrowphase(const ColModel& cm, const DevData& d, const ColData& c, long e, int slot,
-                                       unsigned* acc = nullptr) {
+                                       unsigned* acc, MprState& M) {
   const long E = d.E;
   if (slot >= AT(c.ncand, 0)) return;
   const int p = AT(c.cand_pair, slot);
@@ -479,7 +487,7 @@ __device__ inline void col_narrowphase(const ColModel& cm, const DevData& d, con
     a.margin = 0.5 * margin; b.margin = 0.5 * margin;
     double depth;
     int iters = 0;
-    if (mpr_penetration(a, b, cm.mpr_tolerance, cm.mpr_iterations, depth, nrm, pos, iters)) {
+    if (mpr_penetration(a, b, cm.mpr_tolerance, cm.mpr_iterations, depth, nrm, pos, iters, M)) {
       if (!(nrm.x == 0 && nrm.y == 0 && nrm.z == 0)) { hit = true; dist = margin - depth; }
     }
     if (acc) { acc[0] += 1; acc[1] += (unsigned)iters; }
