@@ -172,6 +172,9 @@ def main():
     ap.add_argument("--contacts", action="store_true",
                     help="BASELINE.json configs[2] shape instead of configs[1]: mesh self-collision enabled "
                          "(use with --envs 65536); not the default bench line")
+    ap.add_argument("--hull-verts", type=int, default=0,
+                    help="with --contacts: OPT-IN hull simplification to at most this many vertices per hull "
+                         "(changes the contact geometry; reported separately, never the parity configuration)")
     ap.add_argument("--mixed", action="store_true",
                     help="BASELINE.json configs[3]: three hands in one mixed-model batch, Newton and PGS; "
                          "not the default bench line")
@@ -201,6 +204,9 @@ def main():
         model = workload.contact_free(model)
     else:
         model = workload.with_ground_plane(model, z=-0.05)
+        if args.hull_verts > 0:
+            from mujoco_amd.meshproc import simplify_model_hulls
+            model = simplify_model_hulls(model, args.hull_verts)
     E = args.envs
     seed = 1234 + 1000 * rank
     q, v = workload.config2_state(model, E, seed=seed)
@@ -309,6 +315,9 @@ def main():
                                          "self-collision + a ground plane at z=-0.05 (the plane is this build's "
                                          "augmentation, not in the reference XML), Euler + Newton, fp64")
             out["config"]["collision"] = cstat
+            if args.hull_verts > 0:
+                out["config"]["workload"] += f"; OPT-IN simplified hulls (<= {args.hull_verts} vertices each): NOT the parity geometry"
+                out["config"]["hull_verts"] = args.hull_verts
             out["roofline"]["kernel"] = "k_tp_col+k_c_narrow_flat+k_tpc (one step = 3 launches)"
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(model)

@@ -186,3 +186,53 @@ def load_mesh(name, path, scale, inertia_mode="legacy", need_hull=True):
     if np.prod(scale) < 0:
         tris = tris[:, ::-1, :]
     return CompiledMesh(name, tris, inertia_mode, need_hull)
+
+
+def fibonacci_directions(n):
+    """n roughly uniform unit vectors (Fibonacci lattice)."""
+    k = np.arange(n) + 0.5
+    phi = np.arccos(1 - 2 * k / n)
+    theta = np.pi * (1 + 5 ** 0.5) * k
+    return np.stack([np.cos(theta) * np.sin(phi), np.sin(theta) * np.sin(phi), np.cos(phi)], axis=1)
+
+
+def simplify_hull(hull_verts, max_verts=128):
+    """Inner approximation of a convex hull with at most `max_verts` vertices: the support vertices
+    of the hull along `max_verts` evenly spread directions (plus the six axis extremes), re-hulled.
+    Every kept vertex is a vertex of the original, so the simplified hull lies inside it: contacts
+    can only appear later / be shallower, never earlier.  Returns (verts, faces, adj_start, adj)."""
+    hv = np.asarray(hull_verts, dtype=np.float64)
+    if len(hv) <= max_verts:
+        return convex_hull(hv)
+    n = max_verts
+    while True:
+        dirs = np.concatenate([fibonacci_directions(max(n - 6, 4)), np.eye(3), -np.eye(3)])
+        keep = np.unique(np.argmax(hv @ dirs.T, axis=0))
+        out = convex_hull(hv[keep])
+        if len(out[0]) <= max_verts or n <= 8:
+            return out
+        n -= max(1, (len(out[0]) - max_verts))
+
+
+def simplify_model_hulls(model, max_verts=128):
+    """SURVEY.md §8 f-3 (the GPU-side analogue of the reference's `reduce_mesh`, src/utils.py:8-74):
+    an OPT-IN accuracy/throughput knob.  Replaces every collision hull of `model` by its
+    `simplify_hull`; inertias, frames and bounding radii stay those of the full meshes.  Changes the
+    contact geometry, so it is off for every parity run and reported separately."""
+    m = model.copy()
+    hv, hs, ha, hf = [], [], [], []
+    vadr = aadr = fadr = 0
+    m.mesh_vertadr, m.mesh_vertnum = m.mesh_vertadr.copy(), m.mesh_vertnum.copy()
+    m.mesh_adjadr, m.mesh_faceadr, m.mesh_facenum = m.mesh_adjadr.copy(), m.mesh_faceadr.copy(), m.mesh_facenum.copy()
+    for i in range(len(model.mesh_vertadr)):
+        a, n = int(model.mesh_vertadr[i]), int(model.mesh_vertnum[i])
+        v, f, s0, adj = simplify_hull(model.hull_vert[a:a + n], max_verts)
+        m.mesh_vertadr[i], m.mesh_vertnum[i], m.mesh_adjadr[i] = vadr, len(v), aadr
+        m.mesh_faceadr[i], m.mesh_facenum[i] = fadr, len(f)
+        hv.append(v); hs.append(s0[:-1] + aadr); ha.append(adj); hf.append(f)
+        vadr += len(v); aadr += len(adj); fadr += len(f)
+    m.hull_vert = np.concatenate(hv) if hv else np.zeros((0, 3))
+    m.hull_adj_start = np.concatenate(hs + [np.array([aadr])]).astype(np.int32)
+    m.hull_adj = np.concatenate(ha).astype(np.int32) if ha else np.zeros(0, dtype=np.int32)
+    m.hull_face = np.concatenate(hf).astype(np.int32) if hf else np.zeros((0, 3), dtype=np.int32)
+    return m

@@ -602,3 +602,26 @@ def test_vec_env_rollout(hand_model):
     o4, r4, d4, info = env.step(act)
     assert bool(d4[7]) and int(d4.sum()) == 1 and bool(info["failed"][7])
     assert int(sim.data.warning.abs().max()) == 0
+
+
+def test_simplified_hulls_keep_parity(hand_model):
+    """The opt-in hull simplification changes the geometry, not the agreement: device and oracle on
+    the SAME simplified model still find the same contacts and accelerations."""
+    import torch
+    from mujoco_amd import BatchSim, workload
+    from mujoco_amd.meshproc import simplify_model_hulls
+    m = simplify_model_hulls(hand_model, 64)
+    E = 40
+    q, v = workload.config2_state(m, E, seed=8)
+    c = workload.config2_ctrl(m, E, seed=8)
+    sim = BatchSim(m, n_envs=E)
+    sim.data.qpos.copy_(torch.as_tensor(q)); sim.data.ctrl.copy_(torch.as_tensor(c))
+    sim.step(3); sim.sync()
+    qacc = sim.data.qacc.cpu().numpy()
+    total = 0
+    for e in range(0, E, 4):
+        ref, s = _oracle_forward(m, q[e], v[e] * 0, c[e], ["qacc"], steps=3)
+        assert sorted((a, b) for a, b, _ in sim.data.contacts(e)) == sorted((cc["geom1"], cc["geom2"]) for cc in s.contacts())
+        assert np.abs(qacc[e] - ref["qacc"]).max() / max(1.0, np.abs(ref["qacc"]).max()) < 1e-8
+        total += s.ncon
+    assert total > 5

@@ -155,3 +155,22 @@ def test_contact_rows_and_friction_cone(tmp_path):
     assert s.efc("type").tolist() == [6, 6, 6, 6]
     R = s.efc("R")
     assert np.allclose(R, R[0])
+
+
+def test_hull_simplification_is_an_inner_approximation(hand_model):
+    """SURVEY.md §8 f-3 knob: simplified hulls keep only original hull vertices (so they lie inside
+    the original), respect the vertex budget and stay closed convex polytopes (Euler's formula)."""
+    from mujoco_amd.meshproc import simplify_model_hulls
+    s = simplify_model_hulls(hand_model, 96)
+    assert (s.mesh_vertnum <= 96).all() and (s.mesh_vertnum >= 20).all()
+    d = np.random.default_rng(1).normal(size=(300, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    for i in range(len(s.mesh_vertadr)):
+        a, n = hand_model.mesh_vertadr[i], hand_model.mesh_vertnum[i]
+        b, k = s.mesh_vertadr[i], s.mesh_vertnum[i]
+        full, simp = hand_model.hull_vert[a:a + n], s.hull_vert[b:b + k]
+        assert ((simp @ d.T).max(0) <= (full @ d.T).max(0) + 1e-15).all()
+        assert all((np.abs(full - v).sum(1) == 0).any() for v in simp)            # subset of the original vertices
+        nedge = (s.hull_adj_start[b + k] - s.hull_adj_start[b]) // 2
+        assert k - nedge + s.mesh_facenum[i] == 2                                   # V - E + F = 2
+    assert np.array_equal(s.body_mass, hand_model.body_mass) and np.array_equal(s.geom_rbound, hand_model.geom_rbound)
