@@ -165,6 +165,8 @@ static void build_tp(bs_model* m) {
     at(TPI_ANCMASK, b) = (int32_t)mask;
   }
   m->tp.maxdepth = maxdepth; m->tp.maxdd = maxdd; m->tp.nroots = nroots;
+  m->tp.jump_rounds = 0;
+  while ((1 << m->tp.jump_rounds) < maxdepth) m->tp.jump_rounds++;
   m->tp_ok = 1;
 }
 

@@ -45,6 +45,7 @@ enum { TPL_BCHILD = 0, TPL_DCHILD = TP_MAXC, TPL_ANCMASK = 2 * TP_MAXC, TPL_TOTA
 struct TpModel {
   const int* lane;  // [TPI_TOTAL][32]
   int maxdepth, maxdd, nroots;
+  int jump_rounds;  // ceil(log2(maxdepth)): pointer-jumping rounds that reach the world from every body
   int roots[4];
   int lvl_bchild[34];          // max #children over bodies at depth L-1, indexed by child depth L
   int lvl_dchild[TP_MAXD + 2]; // max #dof-children over dofs with dd == D-1, indexed by D
@@ -87,6 +88,50 @@ __device__ __forceinline__ int env_sum_i(int v) {
 __device__ __forceinline__ bool env_any(bool p, int base) {
   const unsigned long long b = __ballot(p);
   return ((b >> base) & 0xffffffffull) != 0;
+}
+// Root-to-body recursions by pointer jumping instead of one pass per tree level: every lane
+// starts with its own term and the address of its parent's lane; a round adds (composes) what the
+// jump target has gathered so far and then jumps as far again, so ceil(log2(depth)) rounds replace
+// `depth` levels and no lane sits out a round.  The world lane and the lanes beyond nbody hold
+// zeros / the identity and point at themselves.
+template <int N>
+__device__ __forceinline__ void tp_chain_sum(double* v, int par_sa, int rounds, bool isb) {
+  int jp = par_sa;
+  for (int r = 0; r < rounds; r++) {
+    double w[N];
+#pragma unroll
+    for (int k = 0; k < N; k++) w[k] = bperm(v[k], jp);
+    const int jn = __builtin_amdgcn_ds_bpermute(jp, jp);
+    if (isb)
+#pragma unroll
+      for (int k = 0; k < N; k++) v[k] += w[k];
+    jp = jn;
+  }
+}
+// world pose of every body from the poses relative to the parent (lp, lq); quaternions are
+// normalised after every composition, as mj_kinematics normalises every body's
+__device__ __forceinline__ void tp_chain_pose(V3& pos, Q4& quat, const V3& lp, const Q4& lq, int par_sa, int world_sa,
+                                              int rounds, bool isb) {
+  auto unit = [](Q4& q) {
+    const double inv = 1.0 / sqrt(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
+    q.w *= inv; q.x *= inv; q.y *= inv; q.z *= inv;
+  };
+  pos = {0, 0, 0};
+  quat = {1, 0, 0, 0};
+  if (isb) { pos = lp; quat = lq; unit(quat); }
+  int jp = par_sa;
+  for (int r = 0; r < rounds; r++) {
+    const V3 pp = {bperm(pos.x, jp), bperm(pos.y, jp), bperm(pos.z, jp)};
+    const Q4 pq = {bperm(quat.w, jp), bperm(quat.x, jp), bperm(quat.y, jp), bperm(quat.z, jp)};
+    const int jn = __builtin_amdgcn_ds_bpermute(jp, jp);
+    if (isb && jp != world_sa) {
+      const V3 tt = mrot(q2m(pq), pos);
+      pos = {pp.x + tt.x, pp.y + tt.y, pp.z + tt.z};
+      quat = qmul(pq, quat);
+      unit(quat);
+    }
+    jp = jn;
+  }
 }
 __device__ __forceinline__ constexpr int pair_idx(int a, int b) {  // 1 <= a <= b <= TP_MAXD-1
   return (a - 1) * (TP_MAXD - 1) - (a - 1) * (a - 2) / 2 + (b - a);
@@ -452,20 +497,9 @@ __device__ __forceinline__ void tp_collide_prep(const DevModel& m, const TpModel
       lp = {bpos.x + dl.x, bpos.y + dl.y, bpos.z + dl.z};
     }
   }
-  V3 pos = {0, 0, 0};
-  Q4 quat = {1, 0, 0, 0};
-  for (int lvl = 1; lvl <= t.maxdepth; lvl++) {
-    const V3 pp = {bperm(pos.x, par_sa), bperm(pos.y, par_sa), bperm(pos.z, par_sa)};
-    const Q4 pq = {bperm(quat.w, par_sa), bperm(quat.x, par_sa), bperm(quat.y, par_sa), bperm(quat.z, par_sa)};
-    if (isb && depth == lvl) {
-      const V3 tt = mrot(q2m(pq), lp);
-      pos = {pp.x + tt.x, pp.y + tt.y, pp.z + tt.z};
-      quat = qmul(pq, lq);
-      const double n2 = quat.w * quat.w + quat.x * quat.x + quat.y * quat.y + quat.z * quat.z;
-      const double inv = 1.0 / sqrt(n2);
-      quat.w *= inv; quat.x *= inv; quat.y *= inv; quat.z *= inv;
-    }
-  }
+  V3 pos;
+  Q4 quat;
+  tp_chain_pose(pos, quat, lp, lq, par_sa, base * 4, t.jump_rounds, isb);
   // geom frames: lane = geom (chunks of 32), body pose fetched from the body's lane
   const tp_lds_d G = (tp_lds_d)gfr + (tid / TP_LPE) * (cm.ngeom * TPG_SLOT);
   for (int g0 = 0; g0 < cm.ngeom; g0 += TP_LPE) {
@@ -651,20 +685,9 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
         }
       }
       TPC_T(19)
-      V3 pos = {0, 0, 0};
-      Q4 quat = {1, 0, 0, 0};
-      for (int lvl = 1; lvl <= t.maxdepth; lvl++) {
-        const V3 pp = {bperm(pos.x, par_sa), bperm(pos.y, par_sa), bperm(pos.z, par_sa)};
-        const Q4 pq = {bperm(quat.w, par_sa), bperm(quat.x, par_sa), bperm(quat.y, par_sa), bperm(quat.z, par_sa)};
-        if (isb && depth == lvl) {
-          const V3 tt = mrot(q2m(pq), lp);
-          pos = {pp.x + tt.x, pp.y + tt.y, pp.z + tt.z};
-          quat = qmul(pq, lq);
-          const double n2 = quat.w * quat.w + quat.x * quat.x + quat.y * quat.y + quat.z * quat.z;
-          const double inv = 1.0 / sqrt(n2);
-          quat.w *= inv; quat.x *= inv; quat.y *= inv; quat.z *= inv;
-        }
-      }
+      V3 pos;
+      Q4 quat;
+      tp_chain_pose(pos, quat, lp, lq, par_sa, base * 4, t.jump_rounds, isb);
       if (!FULL && stage == 0 && step == nsteps - 1 && env_ok && dump >= 1 && l < m.nbody) {
         // body poses are outputs of the step: stored here so they need not stay live
         AT(d.xpos, 3 * b) = pos.x; AT(d.xpos, 3 * b + 1) = pos.y; AT(d.xpos, 3 * b + 2) = pos.z;
@@ -776,22 +799,23 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
       // ---- A8 comVel + rne bias
       double cvel[6], qfrc_bias;
       {
-        double acc[6] = {0, 0, 0, 0, 0, 0};
+        // cvel = sum of cdof * qvel over the body's chain; cacc = -gravity + sum over the chain of
+        // (parent's cvel x cdof) * qvel: two chain sums and one parent fetch instead of one pass per level
+        double acc[6];
 #pragma unroll
-        for (int k = 0; k < 6; k++) cvel[k] = 0;
-        if (l == 0 && !(m.disableflags & BS_DSBL_GRAVITY)) {
-          acc[3] = -m.gravity[0]; acc[4] = -m.gravity[1]; acc[5] = -m.gravity[2];
+        for (int k = 0; k < 6; k++) cvel[k] = isb ? cdof[k] * qvel : 0.0;
+        tp_chain_sum<6>(cvel, par_sa, t.jump_rounds, isb);
+        {
+          double pv[6], cdd[6];
+#pragma unroll
+          for (int k = 0; k < 6; k++) pv[k] = bperm(cvel[k], par_sa);
+          cross_motion(cdd, pv, cdof);
+#pragma unroll
+          for (int k = 0; k < 6; k++) acc[k] = isb ? cdd[k] * qvel : 0.0;
         }
-        for (int lvl = 1; lvl <= t.maxdepth; lvl++) {
-          double pv[6], pa[6];
-#pragma unroll
-          for (int k = 0; k < 6; k++) { pv[k] = bperm(cvel[k], par_sa); pa[k] = bperm(acc[k], par_sa); }
-          if (isb && depth == lvl) {
-            double cdd[6];
-            cross_motion(cdd, pv, cdof);
-#pragma unroll
-            for (int k = 0; k < 6; k++) { acc[k] = pa[k] + cdd[k] * qvel; cvel[k] = pv[k] + cdof[k] * qvel; }
-          }
+        tp_chain_sum<6>(acc, par_sa, t.jump_rounds, isb);
+        if (isb && !(m.disableflags & BS_DSBL_GRAVITY)) {
+          acc[3] -= m.gravity[0]; acc[4] -= m.gravity[1]; acc[5] -= m.gravity[2];
         }
         double t0[6], t1[6], t2[6], f[6];
         mul_inert_vec(t0, cinert, acc);
@@ -861,15 +885,10 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
       // owner lane reads the spatial vectors of its two bodies and projects their difference
       auto con_jx = [&](double x, double* u3) {
         if constexpr (CON) {
-          double cv[6] = {0, 0, 0, 0, 0, 0};
-          for (int lvl = 1; lvl <= t.maxdepth; lvl++) {
-            double pv[6];
+          double cv[6];
 #pragma unroll
-            for (int k = 0; k < 6; k++) pv[k] = bperm(cv[k], par_sa);
-            if (isb && depth == lvl)
-#pragma unroll
-              for (int k = 0; k < 6; k++) cv[k] = pv[k] + cdof[k] * x;
-          }
+          for (int k = 0; k < 6; k++) cv[k] = isb ? cdof[k] * x : 0.0;
+          tp_chain_sum<6>(cv, par_sa, t.jump_rounds, isb);
           double v1[6], v2[6];
 #pragma unroll
           for (int k = 0; k < 6; k++) { v1[k] = bperm(cv[k], b1_sa); v2[k] = bperm(cv[k], b2_sa); }
