@@ -157,8 +157,8 @@ __device__ __forceinline__ bool reach_tol(const Spt* P, const Spt& v4, const V3&
   const double m = fmin(fmin(dv4 - dot(P[1].v, dir), dv4 - dot(P[2].v, dir)), dv4 - dot(P[3].v, dir));
   return c_is_eq(m, tol) || m < tol;
 }
-__device__ __forceinline__ void expand_portal(Spt* P, const Spt& v4) {
-  const V3 v4v0 = cross(v4.v, P[0].v);
+__device__ __forceinline__ void expand_portal(Spt* P, const V3& p0, const Spt& v4) {
+  const V3 v4v0 = cross(v4.v, p0);
   if (dot(P[1].v, v4v0) > 0) {
     if (dot(P[2].v, v4v0) > 0) P[1] = v4;
     else P[3] = v4;
@@ -211,23 +211,24 @@ __device__ __forceinline__ void swap3(V3& a, V3& b) {
 }
 __device__ __forceinline__ void swap_spt(Spt& a, Spt& b) { swap3(a.v, b.v); swap3(a.v1, b.v1); swap3(a.v2, b.v2); }
 struct MprState {
-  Spt P[4];
+  V3 p0;     // portal point 0 = centre difference (its two support points are the geom centres)
+  Spt P[3];  // portal points 1..3
   V3 d;           // direction of the next support query
   int state, guard, it;
 };
 __device__ __forceinline__ void mpr_begin(MprState& M, const V3& c1, const V3& c2) {
   const V3 origin = {0, 0, 0};
-  M.P[0].v1 = c1; M.P[0].v2 = c2; M.P[0].v = sub(c1, c2);
-  if (v_eq(M.P[0].v, origin)) M.P[0].v = {BS_CCD_EPS * 10, 0, 0};
-  M.P[1] = M.P[0]; M.P[2] = M.P[0]; M.P[3] = M.P[0];
-  M.d = normalized(neg(M.P[0].v));
+  M.p0 = sub(c1, c2);
+  if (v_eq(M.p0, origin)) M.p0 = {BS_CCD_EPS * 10, 0, 0};
+  M.d = normalized(neg(M.p0));
   M.state = 0; M.guard = 0; M.it = 0;
 }
 // consumes the support point `s` of direction M.d; returns 0 = query M.d again, 1 = the inflated
 // hulls intersect (depth, dir = unit normal obj1 -> obj2, pos filled), 2 = they do not
-__device__ __forceinline__ int mpr_step(MprState& M, const Spt& s, double tol, int maxit, double& depth, V3& dir,
-                                        V3& pos, int& iters) {
-  Spt* P = M.P;
+__device__ __forceinline__ int mpr_step(MprState& M, const Spt& s, const V3& c1, const V3& c2, double tol, int maxit,
+                                        double& depth, V3& dir, V3& pos, int& iters) {
+  Spt* P = M.P - 1;  // P[1..3]
+  const V3& p0 = M.p0;
   V3& d = M.d;
   int& state = M.state;
   int& guard = M.guard;
@@ -238,7 +239,7 @@ __device__ __forceinline__ int mpr_step(MprState& M, const Spt& s, double tol, i
     P[1] = s;
     const double dt = dot(P[1].v, d);
     if (c_is_zero(dt) || dt < 0) return 2;
-    d = cross(P[0].v, P[1].v);
+    d = cross(p0, P[1].v);
     if (c_is_zero(dot(d, d))) {
       pos = {0.5 * (P[1].v1.x + P[1].v2.x), 0.5 * (P[1].v1.y + P[1].v2.y), 0.5 * (P[1].v1.z + P[1].v2.z)};
       if (v_eq(P[1].v, origin)) { depth = 0; dir = origin; return 1; }  // touching
@@ -252,8 +253,8 @@ __device__ __forceinline__ int mpr_step(MprState& M, const Spt& s, double tol, i
     P[2] = s;
     const double dt = dot(P[2].v, d);
     if (c_is_zero(dt) || dt < 0) return 2;
-    d = normalized(cross(sub(P[1].v, P[0].v), sub(P[2].v, P[0].v)));
-    if (dot(d, P[0].v) > 0) {
+    d = normalized(cross(sub(P[1].v, p0), sub(P[2].v, p0)));
+    if (dot(d, p0) > 0) {
       swap_spt(P[1], P[2]);
       d = neg(d);
     }
@@ -264,14 +265,14 @@ __device__ __forceinline__ int mpr_step(MprState& M, const Spt& s, double tol, i
     const double dt = dot(P[3].v, d);
     if (c_is_zero(dt) || dt < 0) return 2;
     bool cont = false;
-    double x = dot(cross(P[1].v, P[3].v), P[0].v);
+    double x = dot(cross(P[1].v, P[3].v), p0);
     if (x < 0 && !c_is_zero(x)) { P[2] = P[3]; cont = true; }
     if (!cont) {
-      x = dot(cross(P[3].v, P[2].v), P[0].v);
+      x = dot(cross(P[3].v, P[2].v), p0);
       if (x < 0 && !c_is_zero(x)) { P[1] = P[3]; cont = true; }
     }
     if (cont) {
-      d = normalized(cross(sub(P[1].v, P[0].v), sub(P[2].v, P[0].v)));
+      d = normalized(cross(sub(P[1].v, p0), sub(P[2].v, p0)));
       if (++guard > 100) return 2;
     } else {
       it = 0;
@@ -281,7 +282,7 @@ __device__ __forceinline__ int mpr_step(MprState& M, const Spt& s, double tol, i
     iters++;
     const double y = dot(s.v, d);
     if (!(c_is_zero(y) || y > 0) || reach_tol(P, s, d, tol)) return 2;
-    expand_portal(P, s);
+    expand_portal(P, p0, s);
     it++;
     check_refine = true;
   } else {  // penetration: push the portal to the surface
@@ -293,9 +294,9 @@ __device__ __forceinline__ int mpr_step(MprState& M, const Spt& s, double tol, i
       // position from barycentric coordinates of the origin in the portal tetrahedron
       double bb[4];
       bb[0] = dot(cross(P[1].v, P[2].v), P[3].v);
-      bb[1] = dot(cross(P[3].v, P[2].v), P[0].v);
-      bb[2] = dot(cross(P[0].v, P[1].v), P[3].v);
-      bb[3] = dot(cross(P[2].v, P[1].v), P[0].v);
+      bb[1] = dot(cross(P[3].v, P[2].v), p0);
+      bb[2] = dot(cross(p0, P[1].v), P[3].v);
+      bb[3] = dot(cross(P[2].v, P[1].v), p0);
       double sum = bb[0] + bb[1] + bb[2] + bb[3];
       if (c_is_zero(sum) || sum < 0) {
         bb[0] = 0;
@@ -305,16 +306,16 @@ __device__ __forceinline__ int mpr_step(MprState& M, const Spt& s, double tol, i
         sum = bb[1] + bb[2] + bb[3];
       }
       const double inv = 1.0 / sum;
-      V3 p1 = {0, 0, 0}, p2 = {0, 0, 0};
+      V3 p1 = {0 + bb[0] * c1.x, 0 + bb[0] * c1.y, 0 + bb[0] * c1.z}, p2 = {0 + bb[0] * c2.x, 0 + bb[0] * c2.y, 0 + bb[0] * c2.z};
 #pragma unroll
-      for (int i = 0; i < 4; i++) {
+      for (int i = 1; i < 4; i++) {
         p1.x += bb[i] * P[i].v1.x; p1.y += bb[i] * P[i].v1.y; p1.z += bb[i] * P[i].v1.z;
         p2.x += bb[i] * P[i].v2.x; p2.y += bb[i] * P[i].v2.y; p2.z += bb[i] * P[i].v2.z;
       }
       pos = {0.5 * (p1.x * inv + p2.x * inv), 0.5 * (p1.y * inv + p2.y * inv), 0.5 * (p1.z * inv + p2.z * inv)};
       return 1;
     }
-    expand_portal(P, s);
+    expand_portal(P, p0, s);
     it++;
     d = portal_dir(P);
   }
@@ -337,7 +338,7 @@ __device__ inline bool mpr_penetration(CObj& a, CObj& b, double tol, int maxit, 
   mpr_begin(M, a.xpos, b.xpos);
   for (;;) {
     const Spt s = md_support(a, b, M.d);
-    const int r = mpr_step(M, s, tol, maxit, depth, dir, pos, iters);
+    const int r = mpr_step(M, s, a.xpos, b.xpos, tol, maxit, depth, dir, pos, iters);
     if (r) return r == 1;
   }
 }
@@ -624,7 +625,7 @@ __device__ inline void col_narrow_ws(const ColModel& cm, const DevData& d, const
           Spt s;
           s.v1 = v1; s.v2 = v2; s.v = sub3(v1, v2);
           double depth = 0;
-          const int r = mpr_step(M, s, cm.mpr_tolerance, cm.mpr_iterations, depth, nrm, pos, iters);
+          const int r = mpr_step(M, s, ax, bx, cm.mpr_tolerance, cm.mpr_iterations, depth, nrm, pos, iters);
           if (r) {
             fin = true;
             if (r == 1 && !(nrm.x == 0 && nrm.y == 0 && nrm.z == 0)) { hit = true; dist = margin - depth; }
