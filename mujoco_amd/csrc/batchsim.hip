@@ -74,6 +74,7 @@ struct bs_model {
   int tp_ok = 0;
   std::string tp_why;
   std::vector<int32_t> tp_table;  // [TPI_TOTAL][32]
+  std::vector<double> tp_dtable;  // [TPD_TOTAL][32]
   TpModel tp;
   std::vector<DeviceImage> images;
 };
@@ -163,6 +164,38 @@ static void build_tp(bs_model* m) {
     for (int a = b; a > 0; a = s.body_parentid[a])
       if (jnt_of[a] >= 0) mask |= 1u << a;
     at(TPI_ANCMASK, b) = (int32_t)mask;
+  }
+  // state-independent parts of the constraint rows, with the kernels' own functions
+  std::vector<double>& Dt = m->tp_dtable;
+  Dt.assign((size_t)TPD_TOTAL * TP_LPE, 0.0);
+  auto dat = [&](int f, int l) -> double& { return Dt[(size_t)f * TP_LPE + l]; };
+  DevModel hm;
+  memset(&hm, 0, sizeof hm);
+  hm.disableflags = s.disableflags; hm.timestep = s.timestep;
+  for (int l = 0; l < TP_LPE; l++) dat(TPD_LIM_K, l) = -1.0;
+  for (int b = 1; b < nb; b++) {
+    const int j = jnt_of[b];
+    if (j < 0) continue;
+    const double iw = s.dof_invweight0[j];
+    dat(TPD_IW, b) = iw;
+    double K, B;
+    if (!(s.disableflags & BS_DSBL_FRICTIONLOSS) && s.dof_frictionloss[j] > 0) {
+      const double imp = tp_impedance(s.dof_solimp + 5 * j, 0.0, 0.0);
+      kb_from_solref(hm, s.dof_solref + 2 * j, s.dof_solimp + 5 * j, K, B);
+      const double R = fmax(BS_MINVAL, (1 - imp) * iw / imp);
+      dat(TPD_FRIC_D, b) = 1.0 / R; dat(TPD_FRIC_FL, b) = s.dof_frictionloss[j];
+      dat(TPD_FRIC_RF, b) = R * s.dof_frictionloss[j]; dat(TPD_FRIC_B, b) = B;
+    }
+    if (!(s.disableflags & BS_DSBL_LIMIT) && s.jnt_limited[j]) {
+      kb_from_solref(hm, s.jnt_solref + 2 * j, s.jnt_solimp + 5 * j, K, B);
+      dat(TPD_LIM_K, b) = K; dat(TPD_LIM_B, b) = B;
+    }
+    const int r = at(TPI_EQ_OWN, b);
+    if (r >= 0) {
+      kb_from_solref(hm, m->eq_solref.data() + 2 * r, m->eq_solimp.data() + 5 * r, K, B);
+      dat(TPD_EQ_K, b) = K; dat(TPD_EQ_B, b) = B;
+      dat(TPD_EQ_DIAG, b) = iw + s.dof_invweight0[m->eq_dof2[r]];
+    }
   }
   m->tp.maxdepth = maxdepth; m->tp.maxdd = maxdd; m->tp.nroots = nroots;
   m->tp.jump_rounds = 0;
@@ -535,8 +568,11 @@ static int model_image(bs_model* m, int device, const DeviceImage** out) {
 #undef PUT_CI
 #undef PUT_CD
   TpModel tp = m->tp;
-  tp.lane = nullptr;
-  if (m->tp_ok) fix.push_back({pk.add(m->tp_table.data(), m->tp_table.size() * sizeof(int32_t)), (void**)&tp.lane});
+  tp.lane = nullptr; tp.lane_d = nullptr;
+  if (m->tp_ok) {
+    fix.push_back({pk.add(m->tp_table.data(), m->tp_table.size() * sizeof(int32_t)), (void**)&tp.lane});
+    fix.push_back({pk.add(m->tp_dtable.data(), m->tp_dtable.size() * sizeof(double)), (void**)&tp.lane_d});
+  }
 #undef PUT_I
 #undef PUT_D
   HIPCHK(hipSetDevice(device));

@@ -438,8 +438,8 @@ __device__ inline void impedance(const double* solimp, double pos, double margin
   else y = 1 - pow(1 - x, power) / pow(1 - mid, power - 1);
   imp = dmin + y * (dmax - dmin);
 }
-__device__ inline void kb_from_solref(const DevModel& m, const double* solref, const double* solimp,
-                                      double& K, double& B) {
+__host__ __device__ inline void kb_from_solref(const DevModel& m, const double* solref, const double* solimp,
+                                               double& K, double& B) {
   const double dmax = fmin(fmax(solimp[1], BS_MINIMP), BS_MAXIMP);
   if (solref[0] > 0) {
     double tc = solref[0];

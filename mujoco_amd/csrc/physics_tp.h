@@ -42,8 +42,20 @@ enum {
 // from the table in global memory into registers
 enum { TPL_BCHILD = 0, TPL_DCHILD = TP_MAXC, TPL_ANCMASK = 2 * TP_MAXC, TPL_TOTAL = 2 * TP_MAXC + 1 };
 
+// per-lane constants of the lane's constraint rows, [field][32]: everything in mj_makeImpedance /
+// mj_referenceConstraint that does not depend on the state (K, B of the rows' solref; the whole
+// frictionloss row), evaluated once on the host with the functions the kernels use
+enum {
+  TPD_IW = 0,                                      // dof_invweight0 of the lane's dof
+  TPD_FRIC_D, TPD_FRIC_RF, TPD_FRIC_FL, TPD_FRIC_B,  // D = 1/R (0: no row), R * frictionloss, frictionloss, B
+  TPD_LIM_K, TPD_LIM_B,                            // K < 0: joint not limited
+  TPD_EQ_K, TPD_EQ_B, TPD_EQ_DIAG,                 // of the equality this lane owns
+  TPD_TOTAL
+};
+
 struct TpModel {
   const int* lane;  // [TPI_TOTAL][32]
+  const double* lane_d;  // [TPD_TOTAL][32]
   int maxdepth, maxdd, nroots;
   int jump_rounds;  // ceil(log2(maxdepth)): pointer-jumping rounds that reach the world from every body
   int roots[4];
@@ -318,7 +330,7 @@ struct TpSol {
 };
 
 // impedance with the common power == 2 case evaluated without pow()
-__device__ __forceinline__ double tp_impedance(const double* solimp, double pos, double margin) {
+__host__ __device__ __forceinline__ double tp_impedance(const double* solimp, double pos, double margin) {
   const double dmin = fmin(fmax(solimp[0], BS_MINIMP), BS_MAXIMP), dmax = fmin(fmax(solimp[1], BS_MINIMP), BS_MAXIMP);
   const double width = fmax(solimp[2], BS_MINVAL), mid = fmin(fmax(solimp[3], BS_MINIMP), BS_MAXIMP);
   const double power = fmax(solimp[4], 1.0);
@@ -1017,20 +1029,16 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
       r.Df = r.rf = r.aref_f = r.fl = 0; r.Dl0 = r.Dl1 = r.aref_l0 = r.aref_l1 = 0;
       r.De = r.aref_e = r.ce = 0; r.De_o = r.ce_o = 0; r.own = false; r.cD = cDrow;
       int nact = 0;
+      const double* rc = t.lane_d + l;  // state-independent parts of the rows (host, build_tp)
       if (con_on && has_dof) {
-        const double iw = m.dof_invweight0[j];
-        if (!(m.disableflags & BS_DSBL_FRICTIONLOSS) && m.dof_frictionloss[j] > 0) {
-          double K, B;
-          const double imp = tp_impedance(m.dof_solimp + 5 * j, 0.0, 0.0);
-          kb_from_solref(m, m.dof_solref + 2 * j, m.dof_solimp + 5 * j, K, B);
-          const double R = fmax(BS_MINVAL, (1 - imp) * iw / imp);
-          r.Df = 1.0 / R; r.fl = m.dof_frictionloss[j]; r.rf = R * r.fl; r.aref_f = -B * qvel;
+        const double iw = rc[TPD_IW * TP_LPE], Df = rc[TPD_FRIC_D * TP_LPE], K = rc[TPD_LIM_K * TP_LPE];
+        if (Df > 0) {
+          r.Df = Df; r.fl = rc[TPD_FRIC_FL * TP_LPE]; r.rf = rc[TPD_FRIC_RF * TP_LPE];
+          r.aref_f = -rc[TPD_FRIC_B * TP_LPE] * qvel;
           nact++;
         }
-        if (!(m.disableflags & BS_DSBL_LIMIT) && m.jnt_limited[j]) {
-          const double margin = m.jnt_margin[j];
-          double K, B;
-          kb_from_solref(m, m.jnt_solref + 2 * j, m.jnt_solimp + 5 * j, K, B);
+        if (K >= 0) {
+          const double margin = m.jnt_margin[j], B = rc[TPD_LIM_B * TP_LPE];
           const double d0 = qpos - m.jnt_range[2 * j], d1 = m.jnt_range[2 * j + 1] - qpos;
           if (d0 < margin) {
             const double imp = tp_impedance(m.jnt_solimp + 5 * j, d0, margin);
@@ -1055,10 +1063,8 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
           const double x = qo - m.qpos0[jo];
           const double pos_e = (qpos - qpos0) - (cf[0] + x * (cf[1] + x * (cf[2] + x * (cf[3] + x * cf[4]))));
           const double deriv = cf[1] + x * (2 * cf[2] + x * (3 * cf[3] + x * 4 * cf[4]));
-          const double diag = m.dof_invweight0[j] + m.dof_invweight0[jo];
-          double K, B;
+          const double diag = rc[TPD_EQ_DIAG * TP_LPE], K = rc[TPD_EQ_K * TP_LPE], B = rc[TPD_EQ_B * TP_LPE];
           const double imp = tp_impedance(m.eq_solimp + 5 * eq_own, pos_e, 0.0);
-          kb_from_solref(m, m.eq_solref + 2 * eq_own, m.eq_solimp + 5 * eq_own, K, B);
           r.own = true; r.ce = deriv; r.De = 1.0 / fmax(BS_MINVAL, (1 - imp) * diag / imp);
           r.aref_e = -B * (qvel - deriv * vo) - K * imp * pos_e;
           nact++;
@@ -1403,10 +1409,12 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
     }
   }
 #ifdef TPC_PROFILE
+  TPC_T(11)
   if constexpr (CON) {
-    TPC_T(11)
     if (tid == 0 && cd.stat)
       for (int q = 0; q < 20; q++) atomicAdd(cd.stat + 8 + q, tacc[q]);
+  } else if (blockIdx.x == 7 && tid == 0) {
+    for (int q = 0; q < 20; q++) printf("sec %d %llu\n", q, tacc[q]);
   }
 #endif
   if (!env_ok) return;
