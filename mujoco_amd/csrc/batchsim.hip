@@ -537,6 +537,10 @@ static int model_image(bs_model* m, int device, const DeviceImage** out) {
     const int va = s.mesh_vertadr[me];
     for (int v = 0; v < s.mesh_vertnum[me]; v++) {
       for (int q = 0; q < 3; q++) vert4[4 * ((size_t)va + v) + q] = s.hull_vert[3 * ((size_t)va + v) + q];
+      {
+        const int64_t bits = pack_rec(v, s.hull_adj_start[va + v + 1] - s.hull_adj_start[va + v], s.hull_adj_start[va + v]);
+        memcpy(&vert4[4 * ((size_t)va + v) + 3], &bits, sizeof bits);
+      }
       range[2 * ((size_t)va + v)] = s.hull_adj_start[va + v];
       range[2 * ((size_t)va + v) + 1] = s.hull_adj_start[va + v + 1];
       for (int k = s.hull_adj_start[va + v]; k < s.hull_adj_start[va + v + 1]; k++) {
@@ -599,7 +603,7 @@ struct bs_sim {
   DevModel dm;
   TpModel tp;
   bool use_tp = false;
-  bool narrow_ws = false;
+  bool narrow_ws = false, narrow_blocks = false;
   bool use_tpc = false;  // contacts: tree-parallel dynamics kernel instead of the serial k_c_dyn (steps only)
   bool contacts = false;
   ColModel cm;
@@ -776,8 +780,12 @@ __global__ __launch_bounds__(64) void k_c_broad(ColModel cm, DevData d, ColData 
 // narrowphase over the flattened (environment, candidate slot) items of NB_ENVS environments:
 // an exclusive scan of the candidate counts in LDS, then every lane takes items round-robin, so
 // no lane idles on environments with few candidates and no wavefront is launched for empty slots
-#define NB_ENVS 64
+#ifndef NB_ENVS
+#define NB_ENVS 16
+#endif
+#ifndef NB_THREADS
 #define NB_THREADS 128
+#endif
 __global__ __launch_bounds__(NB_THREADS) void k_c_narrow_flat(ColModel cm, DevData d, ColData c) {
   __shared__ int pre[NB_ENVS + 1];
   __shared__ MprState mpr[NB_THREADS];  // MPR state of every lane (see mpr_penetration)
@@ -860,6 +868,33 @@ __global__ __launch_bounds__(BS_BLOCK) void k_c_dyn(DevModel m, ColModel cm, Dev
   }
 }
 
+// narrowphase over the work list k_tp_col wrote: one lane per item whatever environment it belongs
+// to, so every wavefront but the last is full
+__global__ __launch_bounds__(NB_THREADS) void k_c_narrow_list(ColModel cm, DevData d, ColData c) {
+  __shared__ MprState mpr[NB_THREADS];
+  const int tid = threadIdx.x;
+  const unsigned nhull = (unsigned)c.stat[BS_STAT_ITEMS + d.range], nplane = (unsigned)c.stat[BS_STAT_ITEMS + 4 + d.range];
+  const unsigned plane0 = (nhull + 63u) & ~63u, total = plane0 + nplane;  // plane items start on a wavefront boundary
+  const int* items = c.items + (size_t)d.env0 * cm.maxcand;
+  const int* last = c.items + (size_t)d.n_envs * cm.maxcand - 1;
+  unsigned acc[2] = {0, 0};
+  for (unsigned i = blockIdx.x * NB_THREADS + tid; i < total; i += gridDim.x * NB_THREADS) {
+    if (i >= nhull && i < plane0) continue;
+    const int it = i < nhull ? items[i] : *(last - (i - plane0));
+    col_narrowphase(cm, d, c, d.env0 + (it >> 8), it & 255, acc, mpr[tid]);
+  }
+  if (c.stat) {
+    for (int off = 32; off > 0; off >>= 1) {
+      acc[0] += __shfl_down(acc[0], off, 64);
+      acc[1] += __shfl_down(acc[1], off, 64);
+    }
+    if ((tid & 63) == 0 && acc[0]) {
+      atomicAdd(c.stat, (unsigned long long)acc[0]);
+      atomicAdd(c.stat + 1, (unsigned long long)acc[1]);
+    }
+  }
+}
+
 static inline dim3 grid_for(const bs_sim* s) { return dim3((unsigned)((s->n_envs + BS_BLOCK - 1) / BS_BLOCK)); }
 static inline dim3 grid_tp(const bs_sim* s) { return dim3((unsigned)((s->n_envs + 1) / 2)); }
 // narrowphase: flattened work items by default; BS_NARROW=ws selects the work-stealing variant
@@ -876,8 +911,16 @@ static void launch_narrow(bs_sim* s, const DevData& dd, hipStream_t st) {
 static void launch_tpc_pass(bs_sim* s, const DevData& dd, hipStream_t st, int mode, int dump) {
   const dim3 g((unsigned)((dd.n_envs - dd.env0 + 1) / 2));
   const size_t lds_col = (size_t)2 * s->cm.ngeom * TPG_SLOT * sizeof(double);
+  (void)hipMemsetAsync(s->cd.stat + BS_STAT_ITEMS + dd.range, 0, sizeof(unsigned long long), st);
+  (void)hipMemsetAsync(s->cd.stat + BS_STAT_ITEMS + 4 + dd.range, 0, sizeof(unsigned long long), st);
   hipLaunchKernelGGL(k_tp_col, g, dim3(64), lds_col, st, s->dm, s->tp, dd, s->cm, s->cd);
-  launch_narrow(s, dd, st);
+  if (s->narrow_ws || s->narrow_blocks) {
+    launch_narrow(s, dd, st);
+  } else {
+    size_t nb = ((size_t)(dd.n_envs - dd.env0) * s->cm.maxcand + NB_THREADS - 1) / NB_THREADS;
+    nb = nb < 1 ? 1 : nb > 8192 ? 8192 : nb;
+    hipLaunchKernelGGL(k_c_narrow_list, dim3((unsigned)nb), dim3(NB_THREADS), 0, st, s->cm, dd, s->cd);
+  }
   const int ntri = s->dm.nbody * (s->dm.nbody + 1) / 2;
   const size_t lds = (size_t)(2 * ntri + 2 * TP_LPE * TPC_SLOT + 2 * TP_LPE * 3) * sizeof(double);
   hipLaunchKernelGGL(k_tpc, g, dim3(64), lds, st, s->dm, s->tp, dd, s->cm, s->cd, mode, dump);
@@ -917,6 +960,7 @@ static void launch_step(bs_sim* s, int n_steps) {
       for (int q = 0; q < np; q++) {
         part[q] = s->dd;
         part[q].env0 = q * chunk;
+        part[q].range = q;
         part[q].n_envs = q == np - 1 ? s->n_envs : (q + 1) * chunk;
       }
       (void)hipEventRecord(s->fork_ev, s->stream);
@@ -1004,6 +1048,7 @@ extern "C" int bs_sim_create(const bs_model* const* models, int n_models, const 
   {
     const char* nk = getenv("BS_NARROW");
     s->narrow_ws = nk && strcmp(nk, "ws") == 0;
+    s->narrow_blocks = nk && strcmp(nk, "blocks") == 0;
   }
   if (kv && strcmp(kv, "tp") == 0 && !model->tp_ok) {
     delete s;
@@ -1077,7 +1122,7 @@ extern "C" int bs_sim_create(const bs_model* const* models, int n_models, const 
   if (contacts) {
     const size_t mc = (size_t)s->cm.maxcand, mk = (size_t)s->cm.maxcon, nr = 4 * mk, nh = (size_t)nv * (nv + 1) / 2;
     const size_t drows = mc * 7 + mk * 13 + nr * nv + nr * 5 + nh + (model->d.solver == 0 ? nr * nv : 0);
-    const size_t irows = 1 + mc * 2 + 1 + mk + 1 + mk;
+    const size_t irows = 1 + mc * 3 + 1 + mk + 1 + mk;
     const size_t bytes = drows * E * sizeof(double) + irows * E * sizeof(int) + 512;
     he = hipMalloc(&s->carena, bytes);
     if (he != hipSuccess) {
@@ -1098,7 +1143,7 @@ extern "C" int bs_sim_create(const bs_model* const* models, int n_models, const 
     k.cW = model->d.solver == 0 ? take(nr * nv) : nullptr;
     int* ip = (int*)dp;
     auto takei = [&](size_t rows_) { int* q = ip; ip += rows_ * (size_t)E; return q; };
-    c.ncand = takei(1); c.cand_pair = takei(mc); c.cand_hit = takei(mc);
+    c.ncand = takei(1); c.cand_pair = takei(mc); c.cand_hit = takei(mc); c.items = takei(mc);
     c.ncon = takei(1); c.con_pair = takei(mk);
     k.ncrow = takei(1); k.con_efc = takei(mk);
     c.stat = (unsigned long long*)(((uintptr_t)ip + 7) & ~(uintptr_t)7);

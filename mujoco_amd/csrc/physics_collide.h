@@ -66,12 +66,18 @@ struct ColData {
   double *geom_xpos, *geom_xmat;
   // candidates [maxcand][E]
   int *ncand, *cand_pair, *cand_hit;
+  // narrowphase work list of the tree-parallel path: (env - env0) << 8 | candidate slot.  A range of
+  // environments owns the region [env0 * maxcand, n_envs * maxcand): hull-hull items are packed from
+  // its start (count: stat[BS_STAT_ITEMS + range]), plane-hull items from its end backwards
+  // (stat[BS_STAT_ITEMS + 4 + range]), so the wavefronts of the narrowphase are homogeneous
+  int *items;
   double *cand_dist, *cand_pos, *cand_nrm;
   // contacts [maxcon][E]
   int *ncon, *con_pair;
   double *con_dist, *con_pos, *con_frame;
   // statistics for the work model: narrowphase pairs and MPR support iterations
   unsigned long long *stat;  // [0] narrow pairs, [1] mpr iterations, [2] contacts
+#define BS_STAT_ITEMS 32
 };
 
 __device__ __forceinline__ bool c_is_zero(double x) { return fabs(x) < BS_CCD_EPS; }
@@ -98,9 +104,10 @@ __device__ __forceinline__ int rec_deg(double w) { return (__double2loint(w) >> 
 __device__ __forceinline__ int rec_k0(double w) { return __double2hiint(w); }
 
 struct CObj {
-  const double4 *vert4, *nbr4;  // vert4: this mesh's vertices; nbr4: global adjacency records
-  const int2* range;            // this mesh's vertices
-  const int* start;
+  // vert4: this mesh's vertices, nbr4: global adjacency records, start4: this mesh's start table;
+  // every record is {x, y, z, id | degree << 20 | first adjacency entry << 32}, so a climb step is
+  // one dependent load (the neighbours of the vertex just chosen), not two
+  const double4 *vert4, *nbr4, *start4;
   int cache;
   V3 xpos;
   M3 R;
@@ -112,29 +119,28 @@ __device__ inline V3 hull_support(CObj& o, const V3& dir) {
   const M3& R = o.R;
   const V3 d = {R.a[0] * dir.x + R.a[3] * dir.y + R.a[6] * dir.z, R.a[1] * dir.x + R.a[4] * dir.y + R.a[7] * dir.z,
                 R.a[2] * dir.x + R.a[5] * dir.y + R.a[8] * dir.z};
-  int imax = o.cache, prev = -1;
-  const double4 vc = o.vert4[imax];
+  int prev = -1;
+  const double4 vc = o.vert4[o.cache], vt = o.start4[dir_bin(d.x, d.y, d.z)];
   V3 best = {vc.x, vc.y, vc.z};
-  double vmax = best.x * d.x + best.y * d.y + best.z * d.z;
+  double vmax = best.x * d.x + best.y * d.y + best.z * d.z, rec = vc.w;
   {  // better of (previous support vertex, table vertex for this direction bin) as the start
-    const int t = o.start[dir_bin(d.x, d.y, d.z)];
-    const double4 vt = o.vert4[t];
     const double val = vt.x * d.x + vt.y * d.y + vt.z * d.z;
-    if (val > vmax) { vmax = val; imax = t; best = {vt.x, vt.y, vt.z}; }
+    if (val > vmax) { vmax = val; rec = vt.w; best = {vt.x, vt.y, vt.z}; }
   }
+  int imax = rec_id(rec);
   // steepest ascent over the hull's vertex adjacency; four neighbour records are loaded at a
   // time so the loads overlap
   while (imax != prev) {
     prev = imax;
-    const int2 kr = o.range[prev];
-    for (int k = kr.x; k < kr.y; k += 4) {
+    const int k0 = rec_k0(rec), k1 = k0 + rec_deg(rec);
+    for (int k = k0; k < k1; k += 4) {
       double4 p[4];
 #pragma unroll
-      for (int q = 0; q < 4; q++) p[q] = o.nbr4[k + q < kr.y ? k + q : kr.y - 1];
+      for (int q = 0; q < 4; q++) p[q] = o.nbr4[k + q < k1 ? k + q : k1 - 1];
 #pragma unroll
       for (int q = 0; q < 4; q++) {
         const double val = p[q].x * d.x + p[q].y * d.y + p[q].z * d.z;
-        if (val > vmax) { vmax = val; imax = rec_id(p[q].w); best = {p[q].x, p[q].y, p[q].z}; }
+        if (val > vmax) { vmax = val; rec = p[q].w; imax = rec_id(rec); best = {p[q].x, p[q].y, p[q].z}; }
       }
     }
   }
@@ -457,9 +463,8 @@ __device__ inline void col_narrowphase(const ColModel& cm, const DevData& d, con
   {
     const int mesh = cm.geom_dataid[g2];
     b.vert4 = cm.hull_vert4 + cm.mesh_vertadr[mesh];
-    b.range = cm.hull_range + cm.mesh_vertadr[mesh];
     b.nbr4 = cm.hull_nbr4; b.cache = 0;
-    b.start = cm.hull_start + (size_t)mesh * BS_NSTART;
+    b.start4 = cm.hull_start4 + (size_t)mesh * BS_NSTART;
     b.xpos = {AT(c.geom_xpos, 3 * g2), AT(c.geom_xpos, 3 * g2 + 1), AT(c.geom_xpos, 3 * g2 + 2)};
     for (int k = 0; k < 9; k++) b.R.a[k] = AT(c.geom_xmat, 9 * g2 + k);
   }
@@ -480,9 +485,8 @@ __device__ inline void col_narrowphase(const ColModel& cm, const DevData& d, con
     CObj a;
     const int mesh = cm.geom_dataid[g1];
     a.vert4 = cm.hull_vert4 + cm.mesh_vertadr[mesh];
-    a.range = cm.hull_range + cm.mesh_vertadr[mesh];
     a.nbr4 = cm.hull_nbr4; a.cache = 0;
-    a.start = cm.hull_start + (size_t)mesh * BS_NSTART;
+    a.start4 = cm.hull_start4 + (size_t)mesh * BS_NSTART;
     a.xpos = {AT(c.geom_xpos, 3 * g1), AT(c.geom_xpos, 3 * g1 + 1), AT(c.geom_xpos, 3 * g1 + 2)};
     for (int k = 0; k < 9; k++) a.R.a[k] = AT(c.geom_xmat, 9 * g1 + k);
     a.margin = 0.5 * margin; b.margin = 0.5 * margin;

@@ -53,6 +53,7 @@ struct DevData {
   long E;  // padded environment count = row stride
   long n_envs;  // end of the environment range a launch covers
   long env0;    // its start (tree-parallel contact kernels only: two halves of a batch on two streams)
+  int range;    // index of that range (selects its narrowphase item counter)
   double *qpos, *qvel, *ctrl, *qfrc_applied, *qacc, *qacc_warmstart, *time;
   double *xpos, *xquat, *xipos, *xanchor, *xaxis, *rootcom, *cinert, *crb, *cdof, *qM, *qLD,
       *qLDiagInv;
