@@ -871,16 +871,31 @@ __global__ __launch_bounds__(BS_BLOCK) void k_c_dyn(DevModel m, ColModel cm, Dev
 // narrowphase over the work list k_tp_col wrote: one lane per item whatever environment it belongs
 // to, so every wavefront but the last is full
 __global__ __launch_bounds__(NB_THREADS) void k_c_narrow_list(ColModel cm, DevData d, ColData c) {
+  __shared__ unsigned pre[BS_NSUB + 1];
   __shared__ MprState mpr[NB_THREADS];
   const int tid = threadIdx.x;
-  const unsigned nhull = (unsigned)c.stat[BS_STAT_ITEMS + d.range], nplane = (unsigned)c.stat[BS_STAT_ITEMS + 4 + d.range];
-  const unsigned plane0 = (nhull + 63u) & ~63u, total = plane0 + nplane;  // plane items start on a wavefront boundary
-  const int* items = c.items + (size_t)d.env0 * cm.maxcand;
-  const int* last = c.items + (size_t)d.n_envs * cm.maxcand - 1;
+  if (tid < BS_NSUB) {  // first wavefront: inclusive scan of the sub-list lengths
+    unsigned v = (unsigned)c.stat[BS_STAT_ITEMS + d.range * BS_NSUB + tid];
+    for (int off = 1; off < BS_NSUB; off <<= 1) {
+      const unsigned u = __shfl_up(v, off, 64);
+      if (tid >= off) v += u;
+    }
+    pre[tid + 1] = v;
+    if (tid == 0) pre[0] = 0;
+  }
+  __syncthreads();
+  const unsigned total = pre[BS_NSUB];
+  const int* items = c.items + col_items_base(d.env0, d.range, cm.maxcand);
+  const long subcap = col_items_subcap(d.n_envs - d.env0, cm.maxcand);
   unsigned acc[2] = {0, 0};
   for (unsigned i = blockIdx.x * NB_THREADS + tid; i < total; i += gridDim.x * NB_THREADS) {
-    if (i >= nhull && i < plane0) continue;
-    const int it = i < nhull ? items[i] : *(last - (i - plane0));
+    int lo = 0, hi = BS_NSUB;  // sub-list of item i: largest s with pre[s] <= i
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (pre[mid] <= i) lo = mid;
+      else hi = mid;
+    }
+    const int it = items[lo * subcap + (i - pre[lo])];
     col_narrowphase(cm, d, c, d.env0 + (it >> 8), it & 255, acc, mpr[tid]);
   }
   if (c.stat) {
@@ -911,8 +926,6 @@ static void launch_narrow(bs_sim* s, const DevData& dd, hipStream_t st) {
 static void launch_tpc_pass(bs_sim* s, const DevData& dd, hipStream_t st, int mode, int dump) {
   const dim3 g((unsigned)((dd.n_envs - dd.env0 + 1) / 2));
   const size_t lds_col = (size_t)2 * s->cm.ngeom * TPG_SLOT * sizeof(double);
-  (void)hipMemsetAsync(s->cd.stat + BS_STAT_ITEMS + dd.range, 0, sizeof(unsigned long long), st);
-  (void)hipMemsetAsync(s->cd.stat + BS_STAT_ITEMS + 4 + dd.range, 0, sizeof(unsigned long long), st);
   hipLaunchKernelGGL(k_tp_col, g, dim3(64), lds_col, st, s->dm, s->tp, dd, s->cm, s->cd);
   if (s->narrow_ws || s->narrow_blocks) {
     launch_narrow(s, dd, st);
@@ -1122,8 +1135,10 @@ extern "C" int bs_sim_create(const bs_model* const* models, int n_models, const 
   if (contacts) {
     const size_t mc = (size_t)s->cm.maxcand, mk = (size_t)s->cm.maxcon, nr = 4 * mk, nh = (size_t)nv * (nv + 1) / 2;
     const size_t drows = mc * 7 + mk * 13 + nr * nv + nr * 5 + nh + (model->d.solver == 0 ? nr * nv : 0);
-    const size_t irows = 1 + mc * 3 + 1 + mk + 1 + mk;
-    const size_t bytes = drows * E * sizeof(double) + irows * E * sizeof(int) + 512;
+    const size_t irows = 1 + mc * 2 + 1 + mk + 1 + mk;
+    const size_t nstat = BS_STAT_ITEMS + 4 * BS_NSUB;                 // counters (8 bytes each)
+    const size_t nitems = mc * ((size_t)E + 4 * 2 * BS_NSUB);         // narrowphase work list, 4 ranges at most
+    const size_t bytes = drows * E * sizeof(double) + irows * E * sizeof(int) + 16 + nstat * 8 + nitems * sizeof(int);
     he = hipMalloc(&s->carena, bytes);
     if (he != hipSuccess) {
       (void)hipFree(s->arena); (void)hipStreamDestroy(s->own_stream);
@@ -1143,10 +1158,11 @@ extern "C" int bs_sim_create(const bs_model* const* models, int n_models, const 
     k.cW = model->d.solver == 0 ? take(nr * nv) : nullptr;
     int* ip = (int*)dp;
     auto takei = [&](size_t rows_) { int* q = ip; ip += rows_ * (size_t)E; return q; };
-    c.ncand = takei(1); c.cand_pair = takei(mc); c.cand_hit = takei(mc); c.items = takei(mc);
+    c.ncand = takei(1); c.cand_pair = takei(mc); c.cand_hit = takei(mc);
     c.ncon = takei(1); c.con_pair = takei(mk);
     k.ncrow = takei(1); k.con_efc = takei(mk);
     c.stat = (unsigned long long*)(((uintptr_t)ip + 7) & ~(uintptr_t)7);
+    c.items = (int*)(c.stat + nstat);
     s->fields[BS_F_NCON] = {c.ncon, 1, true};
     // dense Hessian in LDS when (nv(nv+1)/2 + nv) x 64 lanes x 8 B fits one CU's 160 KB
     const size_t want = (nh + (size_t)nv) * BS_BLOCK * sizeof(double);

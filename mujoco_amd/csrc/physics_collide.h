@@ -66,10 +66,10 @@ struct ColData {
   double *geom_xpos, *geom_xmat;
   // candidates [maxcand][E]
   int *ncand, *cand_pair, *cand_hit;
-  // narrowphase work list of the tree-parallel path: (env - env0) << 8 | candidate slot.  A range of
-  // environments owns the region [env0 * maxcand, n_envs * maxcand): hull-hull items are packed from
-  // its start (count: stat[BS_STAT_ITEMS + range]), plane-hull items from its end backwards
-  // (stat[BS_STAT_ITEMS + 4 + range]), so the wavefronts of the narrowphase are homogeneous
+  // narrowphase work list of the tree-parallel path: (env - env0) << 8 | candidate slot.  The
+  // broadphase blocks of a range append to BS_NSUB sub-lists (block index modulo BS_NSUB, so the
+  // append counters stat[BS_STAT_ITEMS + range * BS_NSUB + sub] are not one hot address); sub-list
+  // s of a range starts at col_items_base() + s * col_items_subcap()
   int *items;
   double *cand_dist, *cand_pos, *cand_nrm;
   // contacts [maxcon][E]
@@ -78,7 +78,16 @@ struct ColData {
   // statistics for the work model: narrowphase pairs and MPR support iterations
   unsigned long long *stat;  // [0] narrow pairs, [1] mpr iterations, [2] contacts
 #define BS_STAT_ITEMS 32
+#define BS_NSUB 64
 };
+// capacity of one sub-list: the environments of ceil(blocks / BS_NSUB) broadphase blocks (2 each)
+__host__ __device__ inline long col_items_subcap(long nenv, int maxcand) {
+  return (((nenv + 1) / 2 + BS_NSUB - 1) / BS_NSUB) * 2 * (long)maxcand;
+}
+// first entry of a range's sub-lists: ranges are contiguous in env0, each may round up by 2 * BS_NSUB envs
+__host__ __device__ inline long col_items_base(long env0, int range, int maxcand) {
+  return (env0 + (long)range * 2 * BS_NSUB) * (long)maxcand;
+}
 
 __device__ __forceinline__ bool c_is_zero(double x) { return fabs(x) < BS_CCD_EPS; }
 __device__ __forceinline__ bool c_is_eq(double a, double b) {

@@ -538,7 +538,7 @@ __device__ __forceinline__ void tp_collide_prep(const DevModel& m, const TpModel
   }
   tp_wave_sync();
   // broadphase over the candidate pairs, in pair order
-  int count = 0, nplane = 0;
+  int count = 0;
   for (int p0 = 0; p0 < cm.npair; p0 += TP_LPE) {
     const int p = p0 + l;
     bool keep = false;
@@ -569,40 +569,24 @@ __device__ __forceinline__ void tp_collide_prep(const DevModel& m, const TpModel
     const unsigned bits = (unsigned)(__ballot(keep) >> base);
     const int at = count + __popc(bits & ((1u << l) - 1u));
     if (keep && at < cm.maxcand && env_ok) AT(cd.cand_pair, at) = p;
-    const bool plane = keep && at < cm.maxcand && cm.geom_type[cm.pair_geom1[p]] == BS_GEOM_PLANE;
-    nplane += __popc((unsigned)(__ballot(plane) >> base));
     count += __popc(bits);
   }
   if (l == 0 && env_ok) {
     if (count > cm.maxcand) AT(d.warning, 0) |= 8;
     AT(cd.ncand, 0) = count > cm.maxcand ? cm.maxcand : count;
   }
-  // work list for the narrowphase: the environment reserves consecutive items of each kind
+  // work list for the narrowphase: the environment reserves `count` consecutive items of its sub-list
   if (count > cm.maxcand) count = cm.maxcand;
-  const int nhull = count - nplane;
-  int offh = 0, offp = 0;
-  if (l == 0 && env_ok) {
-    if (nhull > 0) offh = (int)atomicAdd(cd.stat + BS_STAT_ITEMS + d.range, (unsigned long long)nhull);
-    if (nplane > 0) offp = (int)atomicAdd(cd.stat + BS_STAT_ITEMS + 4 + d.range, (unsigned long long)nplane);
-  }
-  offh = __builtin_amdgcn_ds_bpermute(base * 4, offh);
-  offp = __builtin_amdgcn_ds_bpermute(base * 4, offp);
-  tp_wave_sync();  // the candidate pairs written above are read back by other lanes
-  int* hull_items = cd.items + (size_t)d.env0 * cm.maxcand + offh;
-  int* plane_items = cd.items + (size_t)d.n_envs * cm.maxcand - 1 - offp;
-  const int tag = (int)(env - d.env0) << 8;
-  int rh = 0, rp = 0;
-  for (int k0 = 0; k0 < count; k0 += TP_LPE) {
-    const int k = k0 + l;
-    const bool valid = k < count && env_ok;
-    const int p = valid ? AT(cd.cand_pair, k) : 0;
-    const bool plane = valid && cm.geom_type[cm.pair_geom1[p]] == BS_GEOM_PLANE;
-    const unsigned bp = (unsigned)(__ballot(plane) >> base), bh = (unsigned)(__ballot(valid && !plane) >> base);
-    const unsigned lt = (1u << l) - 1u;
-    // __popc returns unsigned: the index must be made signed before it is negated
-    if (plane) plane_items[-(rp + (int)__popc(bp & lt))] = tag | k;
-    else if (valid) hull_items[rh + (int)__popc(bh & lt)] = tag | k;
-    rp += (int)__popc(bp); rh += (int)__popc(bh);
+  const int sub = blockIdx.x & (BS_NSUB - 1);
+  int off = 0;
+  if (l == 0 && env_ok && count > 0)
+    off = (int)atomicAdd(cd.stat + BS_STAT_ITEMS + d.range * BS_NSUB + sub, (unsigned long long)count);
+  off = __builtin_amdgcn_ds_bpermute(base * 4, off);
+  if (env_ok) {
+    int* items = cd.items + col_items_base(d.env0, d.range, cm.maxcand) +
+                 (long)sub * col_items_subcap(d.n_envs - d.env0, cm.maxcand) + off;
+    const int tag = (int)(env - d.env0) << 8;
+    for (int k = l; k < count; k += TP_LPE) items[k] = tag | k;
   }
 }
 
@@ -1446,6 +1430,11 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
     for (int q = 0; q < 20; q++) printf("sec %d %llu\n", q, tacc[q]);
   }
 #endif
+  if constexpr (CON) {
+    // the narrowphase has consumed the work list of this range: clear its append counters for the
+    // next pass (k_tp_col of the next pass starts after this kernel ends)
+    if (blockIdx.x == 0 && cd.stat) cd.stat[BS_STAT_ITEMS + d.range * BS_NSUB + tid] = 0;
+  }
   if (!env_ok) return;
   if (has_dof) {
     AT(d.qpos, j) = qpos; AT(d.qvel, j) = qvel; AT(d.qacc, j) = qacc; AT(d.qacc_warmstart, j) = qacc_ws;
