@@ -198,6 +198,10 @@ static void build_tp(bs_model* m) {
     }
   }
   m->tp.maxdepth = maxdepth; m->tp.maxdd = maxdd; m->tp.nroots = nroots;
+  int mind = maxdepth;
+  for (int b = 1; b < nb; b++)
+    if (jnt_of[b] >= 0 && depth[b] < mind) mind = depth[b];
+  m->tp.fold_minlvl = mind + 1 < 2 ? 2 : mind + 1;
   m->tp.jump_rounds = 0;
   while ((1 << m->tp.jump_rounds) < maxdepth) m->tp.jump_rounds++;
   m->tp_ok = 1;

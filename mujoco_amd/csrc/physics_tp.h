@@ -58,6 +58,7 @@ struct TpModel {
   const double* lane_d;  // [TPD_TOTAL][32]
   int maxdepth, maxdd, nroots;
   int jump_rounds;  // ceil(log2(maxdepth)): pointer-jumping rounds that reach the world from every body
+  int fold_minlvl;  // leaves-to-root folds (crb, rne forces) stop here: no body above this depth carries a dof
   int roots[4];
   int lvl_bchild[34];          // max #children over bodies at depth L-1, indexed by child depth L
   int lvl_dchild[TP_MAXD + 2]; // max #dof-children over dofs with dd == D-1, indexed by D
@@ -792,7 +793,7 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
         double crb[10];
 #pragma unroll
         for (int k = 0; k < 10; k++) crb[k] = cinert[k];
-        for (int lvl = t.maxdepth; lvl >= 2; lvl--) {
+        for (int lvl = t.maxdepth; lvl >= (FULL ? 2 : t.fold_minlvl); lvl--) {
           const bool par = isb && depth == lvl - 1;
           for (int ch = 0; ch < t.lvl_bchild[lvl]; ch++) {
             const int src = tbl[(TPL_BCHILD + ch) * 64 + tid];
@@ -848,7 +849,7 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
         cross_force(t2, cvel, t1);
 #pragma unroll
         for (int k = 0; k < 6; k++) f[k] = isb ? t0[k] + t2[k] : 0.0;
-        for (int lvl = t.maxdepth; lvl >= 2; lvl--) {
+        for (int lvl = t.maxdepth; lvl >= t.fold_minlvl; lvl--) {
           const bool par = isb && depth == lvl - 1;
           for (int ch = 0; ch < t.lvl_bchild[lvl]; ch++) {
             const int src = tbl[(TPL_BCHILD + ch) * 64 + tid];
