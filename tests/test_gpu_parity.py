@@ -423,6 +423,33 @@ def test_work_stealing_narrowphase(hand_model, monkeypatch):
     assert np.abs(res["flat"][0] - res["ws"][0]).max() < 1e-6 * max(1.0, np.abs(res["flat"][0]).max())
 
 
+def test_narrowphase_work_list_is_bitwise_neutral(hand_model, monkeypatch):
+    """The default narrowphase takes its items from the work list the broadphase kernel appends to
+    (order of the list depends on the append race); BS_NARROW=blocks scans the candidate counts per
+    block of environments instead.  Every item writes its own slot, so the results are identical
+    bit for bit, with and without the ground plane, over several steps (counters cleared in between)."""
+    import torch
+    from mujoco_amd import BatchSim, workload
+    for m in (_contact_model(hand_model), workload.with_ground_plane(hand_model, z=-0.05)):
+        E = 333
+        q, v = workload.config2_state(m, E, seed=41)
+        c = workload.config2_ctrl(m, E, seed=41)
+        res = {}
+        for mode in ("list", "blocks"):
+            monkeypatch.setenv("BS_NARROW", mode)
+            sim = BatchSim(m, n_envs=E)
+            sim.data.qpos.copy_(torch.as_tensor(q)); sim.data.ctrl.copy_(torch.as_tensor(c))
+            sim.step(5); sim.sync()
+            res[mode] = [getattr(sim.data, f).cpu().numpy().copy() for f in ("qpos", "qvel", "qacc", "ncon")]
+            st = sim.collision_stats()
+            res[mode].append(np.array([st["narrow_pairs"], st["mpr_iterations"], st["contacts"]]))
+            del sim
+        monkeypatch.delenv("BS_NARROW")
+        assert res["list"][3].sum() > 100
+        for a, b in zip(res["list"], res["blocks"]):
+            assert np.array_equal(a, b)
+
+
 @pytest.mark.parametrize("contacts", [False, True])
 def test_cg_matches_oracle(hand_model, contacts):
     """solver=CG (mj_solCG: Polak-Ribiere with M^-1 as preconditioner, shared primal loop): device vs
