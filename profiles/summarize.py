@@ -48,4 +48,4 @@ print({a: round(b) for a, b in k.items()})
 print("k_tp traffic MB/launch", (2 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024 / 1e6)
 print(out["config1_kernel_stats"])
 print(out["config3_kernel_stats"])
-print({kk: {a: round(b) for a, b in v.items()} for kk, v in out["config3_pmc_per_launch"].items() if kk in ("k_tpc", "k_c_narrow_flat", "k_tp_col")})
+print({kk: {a: round(b) for a, b in v.items()} for kk, v in out["config3_pmc_per_launch"].items() if kk in ("k_tpc", "k_c_narrow_list", "k_tp_col")})
