@@ -1399,6 +1399,18 @@ extern "C" int bs_collision_stats(bs_sim* s, uint64_t out[3], int reset) {
   HIPCHK(hipSetDevice(s->device));
   HIPCHK(hipStreamSynchronize(s->stream));
   HIPCHK(hipMemcpy(out, s->cd.stat, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+#ifdef NP_PROFILE
+  {
+    unsigned long long hc[32], hs[64];
+    HIPCHK(hipMemcpyFromSymbol(hc, HIP_SYMBOL(np_hist_climb), sizeof hc));
+    HIPCHK(hipMemcpyFromSymbol(hs, HIP_SYMBOL(np_hist_sup), sizeof hs));
+    fprintf(stderr, "climb trips per support:");
+    for (int q = 0; q < 32; q++) fprintf(stderr, " %llu", hc[q]);
+    fprintf(stderr, "\nsupport pairs per item:");
+    for (int q = 0; q < 64; q++) fprintf(stderr, " %llu", hs[q]);
+    fprintf(stderr, "\n");
+  }
+#endif
 #ifdef TPC_PROFILE
   {
     uint64_t t[20];

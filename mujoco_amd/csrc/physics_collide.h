@@ -124,7 +124,13 @@ struct CObj {
 };
 struct Spt { V3 v, v1, v2; };
 
+#ifdef NP_PROFILE
+__device__ unsigned long long np_hist_climb[32], np_hist_sup[64];
+#endif
 __device__ inline V3 hull_support(CObj& o, const V3& dir) {
+#ifdef NP_PROFILE
+  int trips = 0;
+#endif
   const M3& R = o.R;
   const V3 d = {R.a[0] * dir.x + R.a[3] * dir.y + R.a[6] * dir.z, R.a[1] * dir.x + R.a[4] * dir.y + R.a[7] * dir.z,
                 R.a[2] * dir.x + R.a[5] * dir.y + R.a[8] * dir.z};
@@ -140,6 +146,9 @@ __device__ inline V3 hull_support(CObj& o, const V3& dir) {
   // steepest ascent over the hull's vertex adjacency; four neighbour records are loaded at a
   // time so the loads overlap
   while (imax != prev) {
+#ifdef NP_PROFILE
+    trips++;
+#endif
     prev = imax;
     const int k0 = rec_k0(rec), k1 = k0 + rec_deg(rec);
     for (int k = k0; k < k1; k += 4) {
@@ -154,13 +163,71 @@ __device__ inline V3 hull_support(CObj& o, const V3& dir) {
     }
   }
   o.cache = imax;
+#ifdef NP_PROFILE
+  atomicAdd(&np_hist_climb[trips < 31 ? trips : 31], 1ull);
+#endif
   const V3 w = mrot(R, best);
   return {o.xpos.x + w.x + o.margin * dir.x, o.xpos.y + w.y + o.margin * dir.y, o.xpos.z + w.z + o.margin * dir.z};
 }
+// support point of the Minkowski difference: the two hill climbs of hull_support (same start
+// rule, same neighbour order, same comparisons) run in ONE loop — a lane climbs hull 1, then
+// hull 2, one batch of four neighbour records per iteration — so a wavefront pays for the longest
+// sum of the two climbs among its lanes, not for the longest climb on each hull
 __device__ inline Spt md_support(CObj& a, CObj& b, const V3& dir) {
+  const V3 da = {a.R.a[0] * dir.x + a.R.a[3] * dir.y + a.R.a[6] * dir.z, a.R.a[1] * dir.x + a.R.a[4] * dir.y + a.R.a[7] * dir.z,
+                 a.R.a[2] * dir.x + a.R.a[5] * dir.y + a.R.a[8] * dir.z};
+  const V3 nd = neg(dir);
+  const V3 db = {b.R.a[0] * nd.x + b.R.a[3] * nd.y + b.R.a[6] * nd.z, b.R.a[1] * nd.x + b.R.a[4] * nd.y + b.R.a[7] * nd.z,
+                 b.R.a[2] * nd.x + b.R.a[5] * nd.y + b.R.a[8] * nd.z};
+  // starts of both climbs: better of (previous support vertex, table vertex of the direction bin)
+  const double4 ca = a.vert4[a.cache], ta = a.start4[dir_bin(da.x, da.y, da.z)];
+  const double4 cb = b.vert4[b.cache], tb = b.start4[dir_bin(db.x, db.y, db.z)];
+  V3 best = {ca.x, ca.y, ca.z};
+  double vmax = best.x * da.x + best.y * da.y + best.z * da.z, rec = ca.w;
+  {
+    const double val = ta.x * da.x + ta.y * da.y + ta.z * da.z;
+    if (val > vmax) { vmax = val; rec = ta.w; best = {ta.x, ta.y, ta.z}; }
+  }
+  V3 best2 = {cb.x, cb.y, cb.z};
+  double vmax2 = best2.x * db.x + best2.y * db.y + best2.z * db.z, rec2 = cb.w;
+  {
+    const double val = tb.x * db.x + tb.y * db.y + tb.z * db.z;
+    if (val > vmax2) { vmax2 = val; rec2 = tb.w; best2 = {tb.x, tb.y, tb.z}; }
+  }
+  V3 d = da, besta = best;
+  const double4* nbr = a.nbr4;  // one global record array for every hull
+  int second = 0, prev = rec_id(rec), imax = prev;
+  int k = rec_k0(rec), k1 = k + rec_deg(rec);
+  for (;;) {
+    double4 p[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) p[q] = nbr[k + q < k1 ? k + q : k1 - 1];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const double val = p[q].x * d.x + p[q].y * d.y + p[q].z * d.z;
+      if (val > vmax) { vmax = val; rec = p[q].w; imax = rec_id(rec); best = {p[q].x, p[q].y, p[q].z}; }
+    }
+    k += 4;
+    if (k < k1) continue;          // more neighbours of this vertex
+    if (imax != prev) {            // moved: scan the new vertex
+      prev = imax; k = rec_k0(rec); k1 = k + rec_deg(rec);
+      continue;
+    }
+    if (second) break;             // both hulls done
+    a.cache = imax; besta = best;  // hull 1 done: switch to hull 2
+    second = 1; d = db; vmax = vmax2; rec = rec2; best = best2;
+    prev = imax = rec_id(rec); k = rec_k0(rec); k1 = k + rec_deg(rec);
+  }
+  b.cache = imax;
   Spt s;
-  s.v1 = hull_support(a, dir);
-  s.v2 = hull_support(b, neg(dir));
+  {
+    const V3 w = mrot(a.R, besta);
+    s.v1 = {a.xpos.x + w.x + a.margin * dir.x, a.xpos.y + w.y + a.margin * dir.y, a.xpos.z + w.z + a.margin * dir.z};
+  }
+  {
+    const V3 w = mrot(b.R, best);
+    s.v2 = {b.xpos.x + w.x + b.margin * nd.x, b.xpos.y + w.y + b.margin * nd.y, b.xpos.z + w.z + b.margin * nd.z};
+  }
   s.v = sub(s.v1, s.v2);
   return s;
 }
@@ -351,9 +418,16 @@ __device__ __forceinline__ int mpr_step(MprState& M, const Spt& s, const V3& c1,
 __device__ inline bool mpr_penetration(CObj& a, CObj& b, double tol, int maxit, double& depth, V3& dir, V3& pos,
                                        int& iters, MprState& M) {
   mpr_begin(M, a.xpos, b.xpos);
+#ifdef NP_PROFILE
+  int nsup = 0;
+#endif
   for (;;) {
     const Spt s = md_support(a, b, M.d);
     const int r = mpr_step(M, s, a.xpos, b.xpos, tol, maxit, depth, dir, pos, iters);
+#ifdef NP_PROFILE
+    nsup++;
+    if (r) atomicAdd(&np_hist_sup[nsup < 63 ? nsup : 63], 1ull);
+#endif
     if (r) return r == 1;
   }
 }
