@@ -610,7 +610,7 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
   int* tbl = sh.tbl;
   const int tid = threadIdx.x;
 #ifdef TPC_PROFILE
-  unsigned long long tacc[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = clock64();
+  unsigned long long tacc[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = clock64();
 #endif
   const int l = tid & (TP_LPE - 1), base = tid & ~(TP_LPE - 1);
   // lane table: lane references become ds_bpermute byte addresses; child lists and ancestor
@@ -644,18 +644,6 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
 #pragma unroll
   for (int D = 0; D < TP_MAXD + 2; D++) c.nchild[D] = t.lvl_dchild[D];
 
-  // packed-triangle coordinates of the entries this lane updates in the dense factorisation
-  int tri_ik[TPC_NTRI];
-  if constexpr (CON) {
-#pragma unroll
-    for (int tt = 0; tt < TPC_NTRI; tt++) {
-      const int q = l + tt * TP_LPE;
-      int i = (int)((sqrtf(8.0f * q + 1.0f) - 1.0f) * 0.5f);
-      if ((i + 1) * (i + 2) / 2 <= q) i++;
-      if (i * (i + 1) / 2 > q) i--;
-      tri_ik[tt] = i | ((q - i * (i + 1) / 2) << 8);
-    }
-  }
   // per-lane model constants
   const int jtype = m.jnt_type[j];
   const double mass = isb ? m.body_mass[b] : 0.0, qpos0 = m.qpos0[j];
@@ -1201,7 +1189,7 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
           // factor: for j = n-1 .. 0  L(j,i) = H(j,i) / sqrt(H(j,j)),  H(i,k) -= L(j,i) L(j,k);
           // the diagonal keeps 1 / L(j,j)
           // the update of column jj touches the packed entries q < tri(jj); they are dealt
-          // round-robin to the 32 lanes (entry q = l + 32 t has row/column tri_ik[t])
+          // round-robin to the 32 lanes (entry q = l + 32 t)
           for (int jj = n - 1; jj >= 0; jj--) {
             const int tj = jj * (jj + 1) / 2;
             const tp_lds_d Hj = Hs + tj;
@@ -1212,16 +1200,24 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
             if (l < jj) Hj[l] = Lji;
             if (l == jj) Hj[jj] = inv;
             tp_wave_sync();
+            TPC_T(20)
 #pragma unroll
             for (int tt = 0; tt < TPC_NTRI; tt++) {
               if (tt * TP_LPE >= tj) break;
               const int q = l + tt * TP_LPE;
               if (q < tj) {
-                const int ik = tri_ik[tt];
-                Hs[q] -= Hj[ik & 0xff] * Hj[ik >> 8];
+                // row / column of packed entry q, recomputed here: a table of them in registers is
+                // spilled, and every spill reload in this loop is a scratch round trip
+                int qq = q;
+                asm volatile("" : "+v"(qq));  // opaque: keeps the compiler from hoisting the table back out of the loops
+                int i = (int)((__fsqrt_rn(8.0f * (float)qq + 1.0f) - 1.0f) * 0.5f);
+                if ((i + 1) * (i + 2) / 2 <= q) i++;
+                if (i * (i + 1) / 2 > q) i--;
+                Hs[q] -= Hj[i] * Hj[q - i * (i + 1) / 2];
               }
             }
             tp_wave_sync();
+            TPC_T(21)
           }
           TPC_T(7)
           // L^T y = g (descending), then L x = y (ascending)
@@ -1426,7 +1422,7 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
   TPC_T(11)
   if constexpr (CON) {
     if (tid == 0 && cd.stat)
-      for (int q = 0; q < 20; q++) atomicAdd(cd.stat + 8 + q, tacc[q]);
+      for (int q = 0; q < 24; q++) atomicAdd(cd.stat + 8 + q, tacc[q]);
   } else if (blockIdx.x == 7 && tid == 0) {
     for (int q = 0; q < 20; q++) printf("sec %d %llu\n", q, tacc[q]);
   }
