@@ -221,12 +221,21 @@ def main():
     from mujoco_amd import dist as bdist
     gather = bdist.ObsGather(sim, world) if world > 1 else None
 
-    def run(nsteps, start_period):
+    launch_events = []  # (start, end, steps) of every bs_step launch of the timed region, on the kernels' stream
+
+    def run(nsteps, start_period, timed=False):
         done, period = 0, start_period
         while done < nsteps:
             n = min(CTRL_PERIOD, nsteps - done)
             sim.data.ctrl.copy_(bank[period % n_bank])
-            sim.step(n)
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                sim.step(n)
+                e1.record()
+                launch_events.append((e0, e1, n))
+            else:
+                sim.step(n)
             if gather is not None:
                 gather.all_gather()
             done += n
@@ -244,7 +253,7 @@ def main():
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()
-    run(args.steps, period)
+    run(args.steps, period, timed=True)
     ev1.record()
     fence()
     wall = time.perf_counter() - t0
@@ -257,18 +266,11 @@ def main():
     iters = float(sim.data.solver_iter.double().mean().item())
     nefc = float(sim.data.nefc.double().mean().item())
 
-    # kernel-only timing with HIP events on the kernel's stream, inside the library: k_step
-    # launches of CTRL_PERIOD steps each (what the timed loop issues)
-    n_launch = 10
-    sim.data.ctrl.copy_(bank[0])
-    kms = []
-    for _ in range(n_launch):
-        ev0.record()
-        sim.step(CTRL_PERIOD)
-        ev1.record()
-        ev1.synchronize()
-        kms.append(ev0.elapsed_time(ev1))
-    k_ms = float(np.mean(kms))
+    # kernel timing: events around every bs_step launch of the timed region (the sim runs on torch's
+    # current stream, so the events sit on the kernels' stream); average per launch of CTRL_PERIOD steps
+    full = [(a.elapsed_time(b), n) for a, b, n in launch_events if n == CTRL_PERIOD] or \
+           [(a.elapsed_time(b) * CTRL_PERIOD / n, n) for a, b, n in launch_events]
+    k_ms = float(np.mean([t for t, _ in full]))
     stage = sim.stage_times()
     cstat = None
     if args.contacts:
