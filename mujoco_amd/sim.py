@@ -144,9 +144,13 @@ class BatchData:
 class BatchSim:
     """`MjSim(model, nsubsteps=1)` for `n_envs` environments stepped in lockstep on one GPU."""
 
-    def __init__(self, model, n_envs=1, device_id=0, nsubsteps=1, use_torch_stream=True):
+    def __init__(self, model, n_envs=1, device_id=0, nsubsteps=1, use_torch_stream=True, max_contacts=0):
+        """`max_contacts`: cap of the contact list per environment (0 = the library's default, 32;
+        further contacts of an environment are dropped in geom-pair order and set warning bit 8)."""
         if n_envs < 1:
             raise ValueError("n_envs must be >= 1")
+        if max_contacts < 0:
+            raise ValueError("max_contacts must be >= 0")
         if nsubsteps < 1:
             raise ValueError("nsubsteps must be >= 1")
         L = _abi.lib()
@@ -159,7 +163,8 @@ class BatchSim:
             self.model = model.model
         h = C.c_void_p()
         models = (C.c_void_p * 1)(self._native.handle)
-        _abi.check(L.bs_sim_create(models, 1, None, self.n_envs, self.device_id, None, C.byref(h)))
+        opt = _abi.Options(max_contacts_per_env=int(max_contacts))
+        _abi.check(L.bs_sim_create(models, 1, None, self.n_envs, self.device_id, C.byref(opt), C.byref(h)))
         self._h = h
         self.data = BatchData(self)
         if use_torch_stream:

@@ -450,6 +450,38 @@ def test_narrowphase_work_list_is_bitwise_neutral(hand_model, monkeypatch):
             assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("kernel", ["tp", "serial"])
+def test_contact_list_overflow(hand_model, kernel, monkeypatch):
+    """More contacts than the cap: the list keeps the first `max_contacts` in geom-pair order (the
+    oracle's order), the environment gets warning bit 8, environments below the cap are untouched."""
+    import torch
+    from mujoco_amd import BatchSim, workload
+    from oracle import OracleSim
+    if kernel == "serial":
+        monkeypatch.setenv("BS_KERNEL", "serial")
+    m = workload.with_ground_plane(hand_model, z=-0.05)
+    E, cap = 96, 2
+    q, v = workload.config2_state(m, E, seed=77)
+    sim = BatchSim(m, n_envs=E, max_contacts=cap)
+    sim.data.qpos.copy_(torch.as_tensor(q))
+    sim.step(1); sim.sync()
+    ncon = sim.data.ncon.cpu().numpy()
+    warn = sim.data.warning.cpu().numpy()
+    assert ncon.max() == cap
+    over = 0
+    for e in range(0, E, 5):
+        s = OracleSim(m)
+        s.qpos[:] = q[e]
+        s.forward()
+        want = [(cc["geom1"], cc["geom2"]) for cc in s.contacts()]
+        got = [(g1, g2) for g1, g2, _ in sim.data.contacts(e)]
+        assert got == want[:cap]
+        assert bool(warn[e] & 8) == (len(want) > cap)
+        over += len(want) > cap
+    assert over > 3
+    assert np.isfinite(sim.data.qacc.cpu().numpy()).all()
+
+
 @pytest.mark.parametrize("contacts", [False, True])
 def test_cg_matches_oracle(hand_model, contacts):
     """solver=CG (mj_solCG: Polak-Ribiere with M^-1 as preconditioner, shared primal loop): device vs
