@@ -651,7 +651,8 @@ __global__ __launch_bounds__(BS_BLOCK) void k_step(DevModel m, DevData d, int ns
 // tree-parallel kernel: 2 environments per 64-lane block (physics_tp.h)
 __global__ __launch_bounds__(64, 2) void k_tp(DevModel m, TpModel t, DevData d, int nsteps, int mode, int dump) {
   __shared__ int tbl[TPL_TOTAL * 64];
-  const TpShared sh = {tbl, nullptr, nullptr, nullptr};
+  __shared__ double park[(TP_MAXD + 1) * 64];
+  const TpShared sh = {tbl, nullptr, nullptr, nullptr, park};
   ColModel cm;
   ColData cd;
   tp_run<false, false, false>(m, t, d, nsteps, mode, dump, sh, cm, cd);
@@ -659,7 +660,7 @@ __global__ __launch_bounds__(64, 2) void k_tp(DevModel m, TpModel t, DevData d, 
 // same with the RK4 integrator (three extra forward passes per step)
 __global__ __launch_bounds__(64, 2) void k_tp_rk4(DevModel m, TpModel t, DevData d, int nsteps, int mode, int dump) {
   __shared__ int tbl[TPL_TOTAL * 64];
-  const TpShared sh = {tbl, nullptr, nullptr, nullptr};
+  const TpShared sh = {tbl, nullptr, nullptr, nullptr, nullptr};
   ColModel cm;
   ColData cd;
   tp_run<false, false, true>(m, t, d, nsteps, mode, dump, sh, cm, cd);
@@ -667,7 +668,7 @@ __global__ __launch_bounds__(64, 2) void k_tp_rk4(DevModel m, TpModel t, DevData
 // same, with every intermediate the parity tests read written out (bs_forward)
 __global__ __launch_bounds__(64, 2) void k_tp_full(DevModel m, TpModel t, DevData d, int nsteps, int mode, int dump) {
   __shared__ int tbl[TPL_TOTAL * 64];
-  const TpShared sh = {tbl, nullptr, nullptr, nullptr};
+  const TpShared sh = {tbl, nullptr, nullptr, nullptr, nullptr};
   ColModel cm;
   ColData cd;
   tp_run<false, true, false>(m, t, d, nsteps, mode, dump, sh, cm, cd);

@@ -160,7 +160,7 @@ typedef int __attribute__((address_space(3))) * tp_lds_i;
 #define TPC_HTRI (TP_LPE * (TP_LPE + 1) / 2)     // packed lower-triangular Hessian, one per env
 #define TPC_NTRI ((TPC_HTRI + TP_LPE - 1) / TP_LPE)
 enum { CG_POS = 0, CG_FRAME = 3, CG_DIST = 12, CG_PAIR = 13, CG_D = 14, CG_MASK = 15, CG_MU = 16 };  // PAIR: pair id | active rows
-struct TpShared { int* tbl; double* H; double* cg; double* U; };
+struct TpShared { int* tbl; double* H; double* cg; double* U; double* park; };  // park: [TP_MAXD + 1][64] or null
 // the two environments of a wavefront diverge, so LDS hand-offs between lanes of one environment
 // are ordered with a fence + scheduling barrier instead of s_barrier (LDS is in-order per wave)
 __device__ __forceinline__ void tp_wave_sync() {
@@ -234,6 +234,64 @@ __device__ TP_HELPER_ATTR TpFac tp_factor(TpCtx c, TpRow Rin) {
   for (int a = 0; a < TP_MAXD; a++) out.R.r[a] = R[a];
   out.dinv = dinv;
   return out;
+}
+
+// two factorisations with the same sparsity at once (M and M + h * damping): the level loop and its
+// cross-lane round trips are shared, so the second factor costs issue slots, not latency
+__device__ TP_HELPER_ATTR void tp_factor2(TpCtx c, TpRow R0in, TpRow R1in, TpFac& out0, TpFac& out1) {
+  double* R[2] = {R0in.r, R1in.r};
+  double A[2][TP_NPAIR];
+#pragma unroll
+  for (int n = 0; n < 2; n++)
+#pragma unroll
+    for (int k = 0; k < TP_NPAIR; k++) A[n][k] = 0;
+  double dinv[2] = {1.0, 1.0};
+#pragma unroll
+  for (int D = TP_MAXD; D >= 1; D--) {
+    if (D > c.maxdd) continue;
+    const bool is = c.dd == D;
+    double T[2][TP_NPAIR];
+#pragma unroll
+    for (int n = 0; n < 2; n++) {
+      const double r0 = is ? R[n][0] : 1.0;
+      const double ir0 = 1.0 / r0;
+#pragma unroll
+      for (int a = 1; a < TP_MAXD; a++) {
+        if (a >= D) continue;
+        const double tmp = R[n][a] * ir0;
+#pragma unroll
+        for (int b = a; b < TP_MAXD; b++) {
+          if (b >= D) continue;
+          T[n][pair_idx(a, b)] = is ? tmp * R[n][b] + A[n][pair_idx(a, b)] : 0.0;
+        }
+        if (is) R[n][a] = tmp;
+      }
+      if (is) dinv[n] = ir0;
+    }
+    if (D == 1) break;
+    const bool par = c.dd == D - 1;
+    for (int ch = 0; ch < c.nchild[D]; ch++) {
+      const int src = c.tbl[(TPL_DCHILD + ch) * 64 + threadIdx.x];
+      const int sa = par && src >= 0 ? src : c.zero_sa;
+#pragma unroll
+      for (int a = 1; a < TP_MAXD; a++) {
+        if (a >= D) continue;
+#pragma unroll
+        for (int b = a; b < TP_MAXD; b++) {
+          if (b >= D) continue;
+#pragma unroll
+          for (int n = 0; n < 2; n++) {
+            const double v = bperm(T[n][pair_idx(a, b)], sa);
+            if (a == 1) R[n][b - 1] -= v;
+            else A[n][pair_idx(a - 1, b - 1)] += v;
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < TP_MAXD; a++) { out0.R.r[a] = R[0][a]; out1.R.r[a] = R[1][a]; }
+  out0.dinv = dinv[0]; out1.dinv = dinv[1];
 }
 
 // x <- (L^T D L)^-1 x (mj_solveM): leaves-to-root sweep, diagonal scale, root-to-leaves sweep
@@ -808,7 +866,21 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
       }
       TPC_T(14)
       // ---- A4 factor M
-      const TpFac LM = tp_factor(c, Mr);
+      // with Euler's implicit damping the step needs the factors of M and of M + h * damping: both
+      // here in one pass when there is LDS to park the second one until the integrator
+      const bool euler_early = !RK4 && !FULL && sh.park && m.damped && mode == 0;
+      TpFac LM;
+      if (euler_early) {
+        TpRow He = Mr;
+        He.r[0] += h * damping;
+        TpFac LE;
+        tp_factor2(c, Mr, He, LM, LE);
+#pragma unroll
+        for (int a = 0; a < TP_MAXD; a++) sh.park[a * 64 + tid] = LE.R.r[a];
+        sh.park[TP_MAXD * 64 + tid] = LE.dinv;
+      } else {
+        LM = tp_factor(c, Mr);
+      }
       TPC_T(15)
       // ---- A8 comVel + rne bias
       double cvel[6], qfrc_bias;
@@ -1396,9 +1468,16 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
         // ---- A12 Euler with implicit joint damping
         double acc = qacc;
         if (m.damped) {
-          TpRow Hr = Mr;
-          Hr.r[0] += h * damping;
-          const TpFac LE = tp_factor(c, Hr);
+          TpFac LE;
+          if (euler_early) {  // own lane's values: no synchronisation needed
+#pragma unroll
+            for (int a = 0; a < TP_MAXD; a++) LE.R.r[a] = sh.park[a * 64 + tid];
+            LE.dinv = sh.park[TP_MAXD * 64 + tid];
+          } else {
+            TpRow Hr = Mr;
+            Hr.r[0] += h * damping;
+            LE = tp_factor(c, Hr);
+          }
           acc = tp_solve(c, LE.R, LE.dinv, has_dof ? qfrc_smooth + qfrc_constraint : 0.0);
         }
         qvel += h * acc;
