@@ -237,12 +237,14 @@ def main():
             else:
                 sim.step(n)
             if gather is not None:
-                gather.all_gather()
+                gather.all_gather(overlap=True)  # under the next period's steps; fence() drains it
             done += n
             period += 1
         return period
 
     def fence():
+        if gather is not None:
+            gather.wait()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()

@@ -22,13 +22,15 @@ def pack_obs(qpos, qvel, ctrl_target, act_joint):
     return torch.cat([qpos, qvel, reward], dim=1).to(torch.float32).contiguous()
 
 
-def all_gather_packed(local, world, group=None, out=None):
-    """[E_local, W] -> [world * E_local, W] on every rank (equal shard sizes)."""
+def all_gather_packed(local, world, group=None, out=None, async_op=False):
+    """[E_local, W] -> [world * E_local, W] on every rank (equal shard sizes).  With `async_op` the
+    collective is only enqueued (on the backend's own stream) and `(out, work)` is returned: the
+    caller's stream goes on with the next physics steps and calls `work.wait()` before it reads `out`."""
     import torch.distributed as dist
     if out is None:
         out = torch.empty((world * local.shape[0], local.shape[1]), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(out, local, group=group)
-    return out
+    work = dist.all_gather_into_tensor(out, local, group=group, async_op=async_op)
+    return (out, work) if async_op else out
 
 
 class ObsGather:
@@ -41,7 +43,23 @@ class ObsGather:
         self.out = torch.empty((world * sim.n_envs, m.nq + m.nv + 1), dtype=torch.float32,
                                device=sim.data.qpos.device)
 
-    def all_gather(self):
+        self._work, self._local = None, None
+
+    def all_gather(self, overlap=False):
+        """Gathers the observations of the state as it is now.  `overlap=True`: the collective runs
+        beside the physics steps enqueued after this call (xGMI traffic under compute); the result
+        is complete after `wait()` (or at the start of the next `all_gather`)."""
+        self.wait()
         d = self.sim.data
-        local = pack_obs(d.qpos, d.qvel, d.ctrl, self.act_joint)
-        return all_gather_packed(local, self.world, self.group, self.out)
+        local = pack_obs(d.qpos, d.qvel, d.ctrl, self.act_joint)  # a snapshot: later steps do not touch it
+        if not overlap:
+            return all_gather_packed(local, self.world, self.group, self.out)
+        self._local = local  # kept alive until the collective has read it
+        _, self._work = all_gather_packed(local, self.world, self.group, self.out, async_op=True)
+        return self.out
+
+    def wait(self):
+        if self._work is not None:
+            self._work.wait()
+            self._work, self._local = None, None
+        return self.out

@@ -117,6 +117,9 @@ out = all_gather_packed(local, world)
 want = pack_obs(qpos_all, qvel_all, ctrl_all, act)
 assert out.shape == (E * world, 2 * nq + 1) and out.dtype == torch.float32
 assert torch.equal(out, want), "gathered observations differ from the unsharded ones"
+out2, work = all_gather_packed(local, world, async_op=True)   # the overlapped form bench.py uses
+work.wait()
+assert torch.equal(out2, want)
 dist.barrier()
 dist.destroy_process_group()
 open(os.path.join({out!r}, f"ok_{{rank}}"), "w").write("ok")
