@@ -194,7 +194,8 @@ def main():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the product path")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    force_dist = bool(os.environ.get("BENCH_FORCE_DIST"))  # rehearsal of the N>1 code path with one rank
+    if world > 1 or force_dist:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
 
@@ -219,7 +220,7 @@ def main():
                                      for k in range(n_bank)])).to(dev)
 
     from mujoco_amd import dist as bdist
-    gather = bdist.ObsGather(sim, world) if world > 1 else None
+    gather = bdist.ObsGather(sim, world) if (world > 1 or force_dist) else None
 
     launch_events = []  # (start, end, steps) of every bs_step launch of the timed region, on the kernels' stream
 

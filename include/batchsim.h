@@ -156,6 +156,13 @@ int bs_sync(bs_sim *s);
 int bs_stage_times(bs_sim *s, double *ms, int n);
 /* Times n_steps of bs_step with HIP events on the sim's stream; returns elapsed ms. */
 int bs_timed_steps(bs_sim *s, int n_steps, double *elapsed_ms);
+/* Observation / reward kernel for the learner glue (the reference has no
+ * environment code, src/Mujoco_XML.py:327-330 is a TODO): one launch on the sim's stream writes, for
+ * every environment e, out[e * row_stride + 0 .. nq) = qpos, [nq .. nq+nv) = qvel (fp32) and
+ * out[e * row_stride + nq + nv] = -sum_u (qpos[joint of actuator u] - ctrl[u])^2, the placeholder
+ * reward of BASELINE.json configs[4].  `out_dev` is device memory of the sim's GPU with room for
+ * n_envs * row_stride floats; row_stride >= nq + nv + 1. */
+int bs_pack_obs(bs_sim *s, float *out_dev, int64_t row_stride);
 
 #ifdef __cplusplus
 }

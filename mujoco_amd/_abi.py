@@ -53,7 +53,7 @@ FIELD_ID = {n: i for i, n in enumerate(FIELD_NAMES)}
 # every symbol include/batchsim.h declares
 SYMBOLS = ("bs_version bs_last_error bs_device_count bs_model_create bs_model_destroy bs_sim_create "
            "bs_sim_destroy bs_set_stream bs_step bs_forward bs_reset bs_get_ptr bs_copy_field "
-           "bs_get_contacts bs_collision_stats bs_sync bs_stage_times bs_timed_steps bs_sim_num_parts bs_sim_part").split()
+           "bs_get_contacts bs_collision_stats bs_sync bs_stage_times bs_timed_steps bs_sim_num_parts bs_sim_part bs_pack_obs").split()
 
 
 class BatchSimError(RuntimeError):
@@ -93,6 +93,7 @@ def lib():
     L.bs_sync.argtypes = [vp]
     L.bs_stage_times.argtypes = [vp, _DP, C.c_int]
     L.bs_timed_steps.argtypes = [vp, C.c_int, _DP]
+    L.bs_pack_obs.argtypes = [vp, vp, C.c_int64]
     for s in SYMBOLS:
         if s not in ("bs_last_error",):
             getattr(L, s).restype = C.c_int

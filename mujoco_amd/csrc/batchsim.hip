@@ -1469,6 +1469,36 @@ extern "C" int bs_stage_times(bs_sim* s, double* ms, int n) {
   return BS_OK;
 }
 
+// obs = qpos | qvel as fp32, reward = -|qpos[actuated joints] - ctrl|^2; lane = environment
+// (coalesced reads of the [row][E] fields; rows of the output are written by their own lane)
+__global__ __launch_bounds__(256) void k_pack_obs(DevModel m, DevData d, float* out, long stride, int nq) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x, E = d.E;
+  if (e >= d.n_envs) return;
+  float* o = out + e * stride;
+  for (int i = 0; i < nq; i++) o[i] = (float)AT(d.qpos, i);
+  for (int i = 0; i < m.nv; i++) o[nq + i] = (float)AT(d.qvel, i);
+  double r = 0;
+  for (int u = 0; u < m.nu; u++) {
+    const double err = AT(d.qpos, m.jnt_qposadr[m.actuator_trnid[u]]) - AT(d.ctrl, u);
+    r += err * err;
+  }
+  o[nq + m.nv] = (float)(-r);
+}
+
+extern "C" int bs_pack_obs(bs_sim* s, float* out_dev, int64_t row_stride) {
+  if (!s || !out_dev) return fail(BS_ERR_INVALID, "bs_pack_obs: null argument");
+  NO_PARTS(s, "bs_pack_obs");
+  const int nq = s->fields[BS_F_QPOS].rows;
+  if (row_stride < nq + s->dm.nv + 1)
+    return fail(BS_ERR_INVALID, "bs_pack_obs: row_stride %lld < nq + nv + 1 = %d", (long long)row_stride,
+                nq + s->dm.nv + 1);
+  HIPCHK(hipSetDevice(s->device));
+  hipLaunchKernelGGL(k_pack_obs, dim3((unsigned)((s->n_envs + 255) / 256)), dim3(256), 0, s->stream, s->dm, s->dd, out_dev,
+                     (long)row_stride, nq);
+  HIPCHK(hipGetLastError());
+  return BS_OK;
+}
+
 extern "C" int bs_timed_steps(bs_sim* s, int n_steps, double* elapsed_ms) {
   if (!s || !elapsed_ms) return fail(BS_ERR_INVALID, "bs_timed_steps: null argument");
   if (n_steps < 1) return fail(BS_ERR_INVALID, "bs_timed_steps: n_steps must be >= 1");

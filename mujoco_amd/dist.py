@@ -43,6 +43,7 @@ class ObsGather:
         self.out = torch.empty((world * sim.n_envs, m.nq + m.nv + 1), dtype=torch.float32,
                                device=sim.data.qpos.device)
 
+        self.local = torch.empty((sim.n_envs, m.nq + m.nv + 1), dtype=torch.float32, device=sim.data.qpos.device)
         self._work, self._local = None, None
 
     def all_gather(self, overlap=False):
@@ -50,8 +51,10 @@ class ObsGather:
         beside the physics steps enqueued after this call (xGMI traffic under compute); the result
         is complete after `wait()` (or at the start of the next `all_gather`)."""
         self.wait()
-        d = self.sim.data
-        local = pack_obs(d.qpos, d.qvel, d.ctrl, self.act_joint)  # a snapshot: later steps do not touch it
+        # a snapshot (later steps do not touch it), written by one kernel (bs_pack_obs); the buffer is
+        # reused: wait() above has ordered this stream after the collective that read it last
+        local = self.local
+        self.sim.pack_obs(local)
         if not overlap:
             return all_gather_packed(local, self.world, self.group, self.out)
         self._local = local  # kept alive until the collective has read it

@@ -230,6 +230,17 @@ class BatchSim:
         _abi.check(_abi.lib().bs_collision_stats(self._h, out, 1 if reset else 0))
         return dict(narrow_pairs=int(out[0]), mpr_iterations=int(out[1]), contacts=int(out[2]))
 
+    def pack_obs(self, out):
+        """obs = qpos | qvel (fp32) and the placeholder reward into `out` ([n_envs, >= nq + nv + 1]
+        fp32 device tensor, rows contiguous): one kernel on the sim's stream (bs_pack_obs)."""
+        m = self.model
+        import torch
+        if (out.dtype != torch.float32 or out.dim() != 2 or out.shape[0] != self.n_envs
+                or out.shape[1] < m.nq + m.nv + 1 or out.stride(1) != 1 or not out.is_cuda):
+            raise ValueError("pack_obs needs a [n_envs, >= nq + nv + 1] fp32 CUDA tensor with contiguous rows")
+        _abi.check(_abi.lib().bs_pack_obs(self._h, C.c_void_p(out.data_ptr()), int(out.stride(0))))
+        return out
+
     def timed_steps(self, n):
         ms = C.c_double()
         _abi.check(_abi.lib().bs_timed_steps(self._h, int(n), C.byref(ms)))

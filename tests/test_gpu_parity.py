@@ -723,3 +723,31 @@ def test_headless_run_simulation_records_trajectory(hand_model, tmp_path):
     # a single environment keeps mujoco-py's shapes in sim.data; the recorder restores the env axis
     r1 = run_simulation(m, 5, n_envs=1)
     assert r1.arrays()["qpos"].shape == (6, 1, m.nq)
+
+
+def test_pack_obs_kernel(hand_model):
+    """bs_pack_obs (obs = qpos | qvel fp32, reward = -|qpos[actuated] - ctrl|^2) against the same
+    thing written with torch ops (`mujoco_amd.dist.pack_obs`); row stride wider than the row."""
+    import torch
+    from mujoco_amd import BatchSim, BatchSimError, workload
+    from mujoco_amd.dist import pack_obs
+    m = workload.contact_free(hand_model)
+    E = 130
+    q, v = workload.config2_state(m, E, seed=8)
+    sim = BatchSim(m, n_envs=E)
+    sim.data.qpos.copy_(torch.as_tensor(q))
+    sim.data.ctrl.copy_(torch.as_tensor(workload.config2_ctrl(m, E, seed=8)))
+    sim.step(7)
+    d = sim.data
+    want = pack_obs(d.qpos, d.qvel, d.ctrl, torch.as_tensor(m.actuator_trnid, dtype=torch.long, device=d.qpos.device))
+    buf = torch.full((E, m.nq + m.nv + 5), -7.0, dtype=torch.float32, device=d.qpos.device)
+    got = sim.pack_obs(buf)
+    torch.cuda.synchronize()
+    W = m.nq + m.nv + 1
+    assert torch.equal(got[:, :W - 1], want[:, :W - 1])
+    assert torch.allclose(got[:, W - 1], want[:, W - 1], rtol=1e-6, atol=0)
+    assert bool((got[:, W:] == -7.0).all())
+    with pytest.raises(ValueError):
+        sim.pack_obs(torch.empty((E, W - 1), dtype=torch.float32, device=d.qpos.device))
+    with pytest.raises(ValueError):
+        sim.pack_obs(torch.empty((E, W), dtype=torch.float64, device=d.qpos.device))
