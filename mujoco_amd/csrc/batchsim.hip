@@ -657,6 +657,15 @@ __global__ __launch_bounds__(64, 2) void k_tp(DevModel m, TpModel t, DevData d, 
   ColData cd;
   tp_run<false, false, false>(m, t, d, nsteps, mode, dump, sh, cm, cd);
 }
+// same with solver = CG (Euler only; bs_forward and RK4 with CG run on the serial kernels)
+__global__ __launch_bounds__(64, 2) void k_tp_cg(DevModel m, TpModel t, DevData d, int nsteps, int mode, int dump) {
+  __shared__ int tbl[TPL_TOTAL * 64];
+  __shared__ double park[(TP_MAXD + 1) * 64];
+  const TpShared sh = {tbl, nullptr, nullptr, nullptr, park};
+  ColModel cm;
+  ColData cd;
+  tp_run<false, false, false, true>(m, t, d, nsteps, mode, dump, sh, cm, cd);
+}
 // same with the RK4 integrator (three extra forward passes per step)
 __global__ __launch_bounds__(64, 2) void k_tp_rk4(DevModel m, TpModel t, DevData d, int nsteps, int mode, int dump) {
   __shared__ int tbl[TPL_TOTAL * 64];
@@ -690,6 +699,14 @@ __global__ __launch_bounds__(64, TPC_OCC) void k_tpc(DevModel m, TpModel t, DevD
   const int ntri = m.nbody * (m.nbody + 1) / 2;
   const TpShared sh = {tbl, tpc_dyn, tpc_dyn + 2 * ntri, tpc_dyn + 2 * ntri + 2 * TP_LPE * TPC_SLOT};
   tp_run<true, false, false>(m, t, d, 1, mode, dump, sh, cm, cd);
+}
+__global__ __launch_bounds__(64, TPC_OCC) void k_tpc_cg(DevModel m, TpModel t, DevData d, ColModel cm, ColData cd, int mode,
+                                                  int dump) {
+  __shared__ int tbl[TPL_TOTAL * 64];
+  extern __shared__ double tpc_dyn[];
+  const int ntri = m.nbody * (m.nbody + 1) / 2;
+  const TpShared sh = {tbl, tpc_dyn, tpc_dyn + 2 * ntri, tpc_dyn + 2 * ntri + 2 * TP_LPE * TPC_SLOT};
+  tp_run<true, false, false, true>(m, t, d, 1, mode, dump, sh, cm, cd);
 }
 __global__ __launch_bounds__(BS_BLOCK) void k_forward(DevModel m, DevData d) {
   const long e = (long)blockIdx.x * BS_BLOCK + threadIdx.x;
@@ -941,7 +958,7 @@ static void launch_tpc_pass(bs_sim* s, const DevData& dd, hipStream_t st, int mo
   }
   const int ntri = s->dm.nbody * (s->dm.nbody + 1) / 2;
   const size_t lds = (size_t)(2 * ntri + 2 * TP_LPE * TPC_SLOT + 2 * TP_LPE * 3) * sizeof(double);
-  hipLaunchKernelGGL(k_tpc, g, dim3(64), lds, st, s->dm, s->tp, dd, s->cm, s->cd, mode, dump);
+  hipLaunchKernelGGL(s->dm.solver == 1 ? k_tpc_cg : k_tpc, g, dim3(64), lds, st, s->dm, s->tp, dd, s->cm, s->cd, mode, dump);
 }
 // check: mj_checkPos/Vel first; integrate: mj_step (Euler) rather than mj_forward; fast: let the
 // tree-parallel kernels run a forward pass too (they leave the position-stage intermediates of
@@ -996,7 +1013,7 @@ static void launch_step(bs_sim* s, int n_steps) {
     return;
   }
   if (s->use_tp)
-    hipLaunchKernelGGL(s->dm.integrator == 1 ? k_tp_rk4 : k_tp, grid_tp(s), dim3(64), 0, s->stream, s->dm, s->tp, s->dd,
+    hipLaunchKernelGGL(s->dm.solver == 1 ? k_tp_cg : s->dm.integrator == 1 ? k_tp_rk4 : k_tp, grid_tp(s), dim3(64), 0, s->stream, s->dm, s->tp, s->dd,
                        n_steps, 0, 1);
   else
     hipLaunchKernelGGL(k_step, grid_for(s), dim3(BS_BLOCK), 0, s->stream, s->dm, s->dd, n_steps);
@@ -1060,8 +1077,10 @@ extern "C" int bs_sim_create(const bs_model* const* models, int n_models, const 
   s->cm = img->cm;
   s->cm.maxcon = (opt && opt->max_contacts_per_env > 0) ? opt->max_contacts_per_env : 32;
   s->cm.maxcand = model->d.npair < 256 ? model->d.npair : 256;
-  s->use_tp = !contacts && model->d.solver == 2 && model->tp_ok && !(kv && strcmp(kv, "serial") == 0);
-  s->use_tpc = contacts && model->d.solver == 2 && model->tp_ok && s->cm.maxcon <= TP_LPE &&
+  // Newton with either integrator, CG with Euler; PGS (dual) stays on the serial kernels
+  const bool tp_solver = model->d.solver == 2 || (model->d.solver == 1 && model->d.integrator == 0);
+  s->use_tp = !contacts && tp_solver && model->tp_ok && !(kv && strcmp(kv, "serial") == 0);
+  s->use_tpc = contacts && tp_solver && model->tp_ok && s->cm.maxcon <= TP_LPE &&
                !(kv && strcmp(kv, "serial") == 0);
   {
     const char* nk = getenv("BS_NARROW");
@@ -1274,7 +1293,7 @@ extern "C" int bs_forward(bs_sim* s) {
   }
   if (s->contacts)
     launch_contact_pass(s, 0, 0);
-  else if (s->use_tp)
+  else if (s->use_tp && s->dm.solver == 2)
     hipLaunchKernelGGL(k_tp_full, grid_tp(s), dim3(64), 0, s->stream, s->dm, s->tp, s->dd, 1, 1, 2);
   else
     hipLaunchKernelGGL(k_forward, grid_for(s), dim3(BS_BLOCK), 0, s->stream, s->dm, s->dd);

@@ -83,6 +83,11 @@ __device__ __forceinline__ double swz16(double v) {  // lane ^ 16 inside each 32
 }
 // all-reduce over the 32 lanes of an environment; every lane gets the bitwise-same sum
 __device__ __forceinline__ double env_sum(double v) {
+  // the argument must be rounded before the first exchange: if the compiler fused a product in the
+  // caller with the first add (fma(x_i, y_i, round(x_j y_j)) in lane i, the mirror image in lane j),
+  // the two lanes of a pair would get sums that differ in the last bit, and every "environment-
+  // uniform" branch downstream (line search, stopping rule) could split the lanes of an environment
+  asm volatile("" : "+v"(v));
   v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
   v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
   v += dpp_mov<0x141>(v);  // row_half_mirror
@@ -662,7 +667,9 @@ __device__ __forceinline__ void tp_collide_prep(const DevModel& m, const TpModel
 // generalized forces of the last forward pass, 2: every intermediate the parity tests read.
 // CON: one step per launch with the contact candidates of k_c_broad / k_c_narrow (physics_collide.h):
 // contact assembly, pyramid rows owned by lanes, dense Hessian per environment in LDS.
-template <bool CON, bool FULL, bool RK4>
+// CG: mj_solCG instead of mj_solNewton (same primal loop, line search and stopping rule; the search
+// direction is Polak-Ribiere in the M^-1 inner product, physics_dev.h::cg_gradient) — no Hessian.
+template <bool CON, bool FULL, bool RK4, bool CG = false>
 __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, const DevData& d, int nsteps,
                                        int mode, int dump, TpShared sh, const ColModel& cm, const ColData& cd) {
   int* tbl = sh.tbl;
@@ -1351,6 +1358,7 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
         s.Ma = use_smooth ? qfrc_smooth : Ma_ws;
         residual(s.qacc, 1.0, s.jf, s.jl0, s.jl1, s.je, s.cj);
         double gauss = 0, cost = 0, oldcost = 0;
+        double cg_grad = 0, cg_Mgrad = 0;  // CG: gradient and M^-1 gradient of the previous iteration
         int iter = 0;
         bool first = true;
         TPC_T(4)
@@ -1378,6 +1386,18 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
           first = false;
           if (iter >= m.iterations) break;
           TPC_T(5)
+          if constexpr (CG) {
+            const double Mg = tp_solve(c, LM.R, LM.dinv, s.grad);  // every lane takes part in the sweeps
+            double beta = 0;
+            if (iter > 0) {
+              const double gg_old = env_sum(cg_grad * cg_Mgrad);
+              const double num = env_sum(s.grad * (Mg - cg_Mgrad));
+              beta = num / (gg_old > BS_MINVAL ? gg_old : BS_MINVAL);
+              if (beta < 0) beta = 0;
+            }
+            s.search = has_dof ? -Mg + (iter > 0 ? beta * s.search : 0.0) : 0.0;
+            cg_grad = s.grad; cg_Mgrad = Mg;
+          } else {
           // H = M + J^T D_active J: without contacts it keeps the dof-tree sparsity
           TpRow Hr = Mr;
           if (has_dof) {
@@ -1400,6 +1420,7 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
           } else {
             const TpFac LH = tp_factor(c, Hr);
             s.search = has_dof ? -tp_solve(c, LH.R, LH.dinv, s.grad) : 0.0;
+          }
           }
           TPC_T(9)
           s.Mv = tp_mul_m(c, Mr, s.search);

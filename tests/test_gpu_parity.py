@@ -517,6 +517,42 @@ def test_cg_matches_oracle(hand_model, contacts):
 
 
 @pytest.mark.parametrize("contacts", [False, True])
+def test_cg_step_tree_parallel(hand_model, contacts, monkeypatch):
+    """bs_step with solver=CG runs in the tree-parallel kernels (k_tp_cg / k_tpc_cg): against the
+    oracle stepping the same environments, and against the serial kernels (BS_KERNEL=serial)."""
+    import torch
+    from mujoco_amd import BatchSim, workload
+    from mujoco_amd.model import SOL_CG
+    from oracle import OracleSim
+    m = hand_model.copy() if contacts else workload.contact_free(hand_model)
+    m.opt_solver = SOL_CG
+    E, n = 40, 5
+    q, v = workload.config2_state(m, E, seed=1237)
+    c = workload.config2_ctrl(m, E, seed=1237)
+    res = {}
+    for kern in ("tp", "serial"):
+        if kern == "serial":
+            monkeypatch.setenv("BS_KERNEL", "serial")
+        sim = BatchSim(m, n_envs=E)
+        sim.data.qpos.copy_(torch.as_tensor(q)); sim.data.ctrl.copy_(torch.as_tensor(c))
+        sim.step(n); sim.sync()
+        res[kern] = [getattr(sim.data, f).cpu().numpy().copy() for f in ("qpos", "qvel", "qacc", "solver_iter")]
+        del sim
+    monkeypatch.delenv("BS_KERNEL")
+    tol = 1e-6 if contacts else 1e-8
+    for a, b in zip(res["tp"][:3], res["serial"][:3]):
+        assert np.abs(a - b).max() <= tol * max(1.0, np.abs(b).max())
+    assert np.abs(res["tp"][3].astype(int) - res["serial"][3].astype(int)).max() <= 1
+    for e in range(0, E, 9):
+        s = OracleSim(m)
+        s.qpos[:] = q[e]; s.ctrl[:] = c[e]
+        s.step(n)
+        assert np.abs(res["tp"][0][e] - s.qpos).max() < tol
+        assert np.abs(res["tp"][1][e] - s.qvel).max() < tol * max(1.0, np.abs(s.qvel).max())
+        assert np.abs(res["tp"][2][e] - s.qacc).max() < 1e-6 * max(1.0, np.abs(s.qacc).max())
+
+
+@pytest.mark.parametrize("contacts", [False, True])
 def test_pgs_matches_oracle(hand_model, contacts):
     """solver=PGS (north_star; BASELINE.json configs[3] 'PGS vs Newton'): device matrix-free PGS vs
     the oracle's explicit-dual PGS, and both near the Newton fixed point."""
