@@ -175,6 +175,8 @@ def main():
     ap.add_argument("--hull-verts", type=int, default=0,
                     help="with --contacts: OPT-IN hull simplification to at most this many vertices per hull "
                          "(changes the contact geometry; reported separately, never the parity configuration)")
+    ap.add_argument("--solver", choices=("newton", "cg", "pgs"), default="newton",
+                    help="constraint solver (default newton, the reference's default; not the default bench line otherwise)")
     ap.add_argument("--mixed", action="store_true",
                     help="BASELINE.json configs[3]: three hands in one mixed-model batch, Newton and PGS; "
                          "not the default bench line")
@@ -208,6 +210,10 @@ def main():
         if args.hull_verts > 0:
             from mujoco_amd.meshproc import simplify_model_hulls
             model = simplify_model_hulls(model, args.hull_verts)
+    if args.solver != "newton":
+        from mujoco_amd.model import SOL_CG, SOL_PGS
+        model = model.copy()
+        model.opt_solver = SOL_CG if args.solver == "cg" else SOL_PGS
     E = args.envs
     seed = 1234 + 1000 * rank
     q, v = workload.config2_state(model, E, seed=seed)
@@ -323,7 +329,15 @@ def main():
             if args.hull_verts > 0:
                 out["config"]["workload"] += f"; OPT-IN simplified hulls (<= {args.hull_verts} vertices each): NOT the parity geometry"
                 out["config"]["hull_verts"] = args.hull_verts
-            out["roofline"]["kernel"] = "k_tp_col+k_c_narrow_flat+k_tpc (one step = 3 launches)"
+            out["roofline"]["kernel"] = "k_tp_col+k_c_narrow_list+k_tpc (one step = 3 launches)"
+        if args.solver != "newton":
+            out["config"]["workload"] += f"; solver = {args.solver.upper()} (non-default)"
+            out["config"]["solver"] = args.solver
+            out["roofline"]["traffic"] = None
+            if args.solver == "cg":
+                out["roofline"]["kernel"] = out["roofline"]["kernel"].replace("k_tpc", "k_tpc_cg") if cstat else "k_tp_cg"
+            else:
+                out["roofline"]["kernel"] = "serial kernels (k_step / k_c_dyn): PGS has no tree-parallel path"
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(model)
             try:
