@@ -787,3 +787,27 @@ def test_pack_obs_kernel(hand_model):
         sim.pack_obs(torch.empty((E, W - 1), dtype=torch.float32, device=d.qpos.device))
     with pytest.raises(ValueError):
         sim.pack_obs(torch.empty((E, W), dtype=torch.float64, device=d.qpos.device))
+
+
+@pytest.mark.parametrize("contacts", [False, True])
+def test_long_rollout_invariants(hand_model, contacts):
+    """Soak: thousands of steps with ctrl resampled every 50 (the bench's loop): no NaN, no
+    mj_check* reset, joints stay inside their ranges up to the soft-constraint penetration."""
+    import torch
+    from mujoco_amd import BatchSim, workload
+    m = workload.with_ground_plane(hand_model, z=-0.05) if contacts else workload.contact_free(hand_model)
+    E, periods = 512, (20 if contacts else 80)
+    q, v = workload.config2_state(m, E, seed=4321)
+    sim = BatchSim(m, n_envs=E)
+    sim.data.qpos.copy_(torch.as_tensor(q))
+    bank = torch.as_tensor(np.stack([workload.config2_ctrl(m, E, seed=4321, resample_idx=k) for k in range(4)])).to(sim.data.ctrl.device)
+    for p in range(periods):
+        sim.data.ctrl.copy_(bank[p % 4])
+        sim.step(50)
+    sim.sync()
+    qp, qv = sim.data.qpos.cpu().numpy(), sim.data.qvel.cpu().numpy()
+    assert np.isfinite(qp).all() and np.isfinite(qv).all()
+    assert int((sim.data.warning != 0).sum().item()) == 0
+    assert np.maximum(m.jnt_range[:, 0] - qp, qp - m.jnt_range[:, 1]).max() < 0.05
+    assert np.abs(qv).max() < 50.0
+    assert abs(float(sim.data.time[0]) - periods * 50 * m.opt_timestep) < 1e-9
