@@ -337,7 +337,7 @@ def main():
             if args.solver == "cg":
                 out["roofline"]["kernel"] = out["roofline"]["kernel"].replace("k_tpc", "k_tpc_cg") if cstat else "k_tp_cg"
             else:
-                out["roofline"]["kernel"] = "serial kernels (k_step / k_c_dyn): PGS has no tree-parallel path"
+                out["roofline"]["kernel"] = "serial kernels (k_c_dyn): PGS with contacts has no tree-parallel path" if cstat else "k_tp_pgs"
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(model)
             try:

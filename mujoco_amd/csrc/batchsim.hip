@@ -75,6 +75,7 @@ struct bs_model {
   std::string tp_why;
   std::vector<int32_t> tp_table;  // [TPI_TOTAL][32]
   std::vector<double> tp_dtable;  // [TPD_TOTAL][32]
+  std::vector<int32_t> tp_pgs;    // PGS sweep order (TpModel::pgs_order)
   TpModel tp;
   std::vector<DeviceImage> images;
 };
@@ -197,6 +198,15 @@ static void build_tp(bs_model* m) {
       dat(TPD_EQ_DIAG, b) = iw + s.dof_invweight0[m->eq_dof2[r]];
     }
   }
+  // PGS sweep order = efc order: equalities, frictionloss rows, limits (lower, upper per joint)
+  m->tp_pgs.clear();
+  for (size_t r = 0; r < m->eq_dof1.size(); r++) m->tp_pgs.push_back(s.dof_bodyid[m->eq_dof1[r]] | (0 << 8));
+  for (size_t k = 0; k < m->fric_dof.size(); k++) m->tp_pgs.push_back(s.dof_bodyid[m->fric_dof[k]] | (1 << 8));
+  for (size_t k = 0; k < m->lim_jnt.size(); k++) {
+    m->tp_pgs.push_back(s.jnt_bodyid[m->lim_jnt[k]] | (2 << 8));
+    m->tp_pgs.push_back(s.jnt_bodyid[m->lim_jnt[k]] | (3 << 8));
+  }
+  m->tp.npgs = (int)m->tp_pgs.size();
   m->tp.maxdepth = maxdepth; m->tp.maxdd = maxdd; m->tp.nroots = nroots;
   int mind = maxdepth;
   for (int b = 1; b < nb; b++)
@@ -576,8 +586,9 @@ static int model_image(bs_model* m, int device, const DeviceImage** out) {
 #undef PUT_CI
 #undef PUT_CD
   TpModel tp = m->tp;
-  tp.lane = nullptr; tp.lane_d = nullptr;
+  tp.lane = nullptr; tp.lane_d = nullptr; tp.pgs_order = nullptr;
   if (m->tp_ok) {
+    fix.push_back({pk.add(m->tp_pgs.data(), m->tp_pgs.size() * sizeof(int32_t)), (void**)&tp.pgs_order});
     fix.push_back({pk.add(m->tp_table.data(), m->tp_table.size() * sizeof(int32_t)), (void**)&tp.lane});
     fix.push_back({pk.add(m->tp_dtable.data(), m->tp_dtable.size() * sizeof(double)), (void**)&tp.lane_d});
   }
@@ -665,6 +676,15 @@ __global__ __launch_bounds__(64, 2) void k_tp_cg(DevModel m, TpModel t, DevData 
   ColModel cm;
   ColData cd;
   tp_run<false, false, false, true>(m, t, d, nsteps, mode, dump, sh, cm, cd);
+}
+// same with solver = PGS (contact-free, Euler): M^-1 of the two environments lives in LDS
+__global__ __launch_bounds__(64, 2) void k_tp_pgs(DevModel m, TpModel t, DevData d, int nsteps, int mode, int dump) {
+  __shared__ int tbl[TPL_TOTAL * 64];
+  __shared__ double minv[2 * TP_LPE * TP_MINV_STRIDE];
+  const TpShared sh = {tbl, nullptr, nullptr, nullptr, nullptr, minv};
+  ColModel cm;
+  ColData cd;
+  tp_run<false, false, false, false, true>(m, t, d, nsteps, mode, dump, sh, cm, cd);
 }
 // same with the RK4 integrator (three extra forward passes per step)
 __global__ __launch_bounds__(64, 2) void k_tp_rk4(DevModel m, TpModel t, DevData d, int nsteps, int mode, int dump) {
@@ -1013,7 +1033,8 @@ static void launch_step(bs_sim* s, int n_steps) {
     return;
   }
   if (s->use_tp)
-    hipLaunchKernelGGL(s->dm.solver == 1 ? k_tp_cg : s->dm.integrator == 1 ? k_tp_rk4 : k_tp, grid_tp(s), dim3(64), 0, s->stream, s->dm, s->tp, s->dd,
+    hipLaunchKernelGGL(s->dm.solver == 0 ? k_tp_pgs : s->dm.solver == 1 ? k_tp_cg : s->dm.integrator == 1 ? k_tp_rk4 : k_tp,
+                       grid_tp(s), dim3(64), 0, s->stream, s->dm, s->tp, s->dd,
                        n_steps, 0, 1);
   else
     hipLaunchKernelGGL(k_step, grid_for(s), dim3(BS_BLOCK), 0, s->stream, s->dm, s->dd, n_steps);
@@ -1077,9 +1098,10 @@ extern "C" int bs_sim_create(const bs_model* const* models, int n_models, const 
   s->cm = img->cm;
   s->cm.maxcon = (opt && opt->max_contacts_per_env > 0) ? opt->max_contacts_per_env : 32;
   s->cm.maxcand = model->d.npair < 256 ? model->d.npair : 256;
-  // Newton with either integrator, CG with Euler; PGS (dual) stays on the serial kernels
+  // Newton with either integrator, CG with Euler; PGS (dual) with Euler and without contacts
   const bool tp_solver = model->d.solver == 2 || (model->d.solver == 1 && model->d.integrator == 0);
-  s->use_tp = !contacts && tp_solver && model->tp_ok && !(kv && strcmp(kv, "serial") == 0);
+  const bool tp_pgs = model->d.solver == 0 && model->d.integrator == 0;
+  s->use_tp = !contacts && (tp_solver || tp_pgs) && model->tp_ok && !(kv && strcmp(kv, "serial") == 0);
   s->use_tpc = contacts && tp_solver && model->tp_ok && s->cm.maxcon <= TP_LPE &&
                !(kv && strcmp(kv, "serial") == 0);
   {

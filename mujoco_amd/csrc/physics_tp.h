@@ -59,6 +59,10 @@ struct TpModel {
   int maxdepth, maxdd, nroots;
   int jump_rounds;  // ceil(log2(maxdepth)): pointer-jumping rounds that reach the world from every body
   int fold_minlvl;  // leaves-to-root folds (crb, rne forces) stop here: no body above this depth carries a dof
+  // PGS sweep order (mj_solPGS visits the rows in efc order: equality, frictionloss, limits): one entry
+  // per possible row, lane | kind << 8 with kind 0 equality (owner lane), 1 frictionloss, 2 lower, 3 upper limit
+  const int* pgs_order;
+  int npgs;
   int roots[4];
   int lvl_bchild[34];          // max #children over bodies at depth L-1, indexed by child depth L
   int lvl_dchild[TP_MAXD + 2]; // max #dof-children over dofs with dd == D-1, indexed by D
@@ -165,7 +169,8 @@ typedef int __attribute__((address_space(3))) * tp_lds_i;
 #define TPC_HTRI (TP_LPE * (TP_LPE + 1) / 2)     // packed lower-triangular Hessian, one per env
 #define TPC_NTRI ((TPC_HTRI + TP_LPE - 1) / TP_LPE)
 enum { CG_POS = 0, CG_FRAME = 3, CG_DIST = 12, CG_PAIR = 13, CG_D = 14, CG_MASK = 15, CG_MU = 16 };  // PAIR: pair id | active rows
-struct TpShared { int* tbl; double* H; double* cg; double* U; double* park; };  // park: [TP_MAXD + 1][64] or null
+struct TpShared { int* tbl; double* H; double* cg; double* U; double* park; double* minv; };  // park: [TP_MAXD + 1][64] or null
+#define TP_MINV_STRIDE 33  // doubles per row of the per-environment M^-1 in LDS (odd: conflict-free columns)
 // the two environments of a wavefront diverge, so LDS hand-offs between lanes of one environment
 // are ordered with a fence + scheduling barrier instead of s_barrier (LDS is in-order per wave)
 __device__ __forceinline__ void tp_wave_sync() {
@@ -669,7 +674,10 @@ __device__ __forceinline__ void tp_collide_prep(const DevModel& m, const TpModel
 // contact assembly, pyramid rows owned by lanes, dense Hessian per environment in LDS.
 // CG: mj_solCG instead of mj_solNewton (same primal loop, line search and stopping rule; the search
 // direction is Polak-Ribiere in the M^-1 inner product, physics_dev.h::cg_gradient) — no Hessian.
-template <bool CON, bool FULL, bool RK4, bool CG = false>
+// PGS: mj_solPGS (dual, projected Gauss-Seidel; contact-free models only): M^-1 is formed column by
+// column in LDS, the sweep visits the rows in efc order, the owner lane of a row computes its new
+// force and broadcasts the change, every dof lane adds change * (M^-1 J^T)_i to its acceleration.
+template <bool CON, bool FULL, bool RK4, bool CG = false, bool PGS = false>
 __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, const DevData& d, int nsteps,
                                        int mode, int dump, TpShared sh, const ColModel& cm, const ColData& cd) {
   int* tbl = sh.tbl;
@@ -1322,6 +1330,96 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
       TPC_T(3)
       if (nefc == 0) {  // env-uniform
         qacc = qacc_smooth; qacc_ws = qacc_smooth; solver_iter = 0;
+      } else if constexpr (PGS) {
+        // ---- A11 mj_solPGS (same arithmetic as physics_contact.h::stage_pgs, contact-free)
+        const tp_lds_d Minv = (tp_lds_d)sh.minv + (size_t)(tid / TP_LPE) * TP_LPE * TP_MINV_STRIDE;
+        const tp_lds_d Mrow = Minv + l * TP_MINV_STRIDE;
+        const unsigned dofs = (unsigned)(__ballot(has_dof) >> base);
+        for (int jl = 1; jl < m.nbody; jl++) {  // M^-1 e_j for every dof (lane jl), one solve each
+          if (!((dofs >> jl) & 1)) continue;
+          Mrow[jl] = tp_solve(c, LM.R, LM.dinv, l == jl ? 1.0 : 0.0);
+        }
+        tp_wave_sync();
+        const int ko = (eq_other_sa >> 2) & (TP_LPE - 1);  // lane of the equality's other dof (own lane if none)
+        const tp_lds_d Orow = Minv + ko * TP_MINV_STRIDE;
+        // (M^-1 J_r^T)_l for the row kinds, J_r (M^-1 J_r^T) + 1/D on the owner lane
+        const double mjj = has_dof ? Mrow[l] : 0.0;
+        const double ARf = mjj + (r.Df > 0 ? 1.0 / r.Df : 0.0), AR0 = mjj + (r.Dl0 > 0 ? 1.0 / r.Dl0 : 0.0),
+                     AR1 = mjj + (r.Dl1 > 0 ? 1.0 / r.Dl1 : 0.0);
+        const double ARe = r.own ? (Mrow[l] - r.ce * Mrow[ko]) - r.ce * (Orow[l] - r.ce * Orow[ko]) + 1.0 / r.De : 1.0;
+        double fF = 0, fL0 = 0, fL1 = 0, fE = 0, acc = qacc_smooth;
+        auto jtf = [&]() -> double {  // J^T f on this lane
+          const double fo = bperm(fE, eq_src_sa);
+          double q = fF + fL0 - fL1 + fE;
+          if (is_src) q -= r.ce_o * fo;
+          return has_dof ? q : 0.0;
+        };
+        if (!(m.disableflags & BS_DSBL_WARMSTART)) {
+          // forces the previous acceleration implies; kept if their dual cost is <= 0
+          const double ao = bperm(qacc_ws, eq_other_sa);
+          const double jf = qacc_ws - r.aref_f, jl0 = qacc_ws - r.aref_l0, jl1 = -qacc_ws - r.aref_l1;
+          const double je = r.own ? (qacc_ws - r.ce * ao) - r.aref_e : 0.0;
+          double f4[4];
+          tp_rows_cost<true>(r, jf, jl0, jl1, je, f4);
+          fF = r.Df > 0 ? f4[0] : 0.0; fL0 = r.Dl0 > 0 ? f4[1] : 0.0; fL1 = r.Dl1 > 0 ? f4[2] : 0.0; fE = r.own ? f4[3] : 0.0;
+          const double w = tp_solve(c, LM.R, LM.dinv, jtf());  // M^-1 J^T f
+          const double wo = bperm(w, eq_other_sa), so = bperm(qacc_smooth, eq_other_sa);
+          double cl = 0;
+          if (r.Df > 0) cl += fF * (0.5 * (w + fF / r.Df) + (qacc_smooth - r.aref_f));
+          if (r.Dl0 > 0) cl += fL0 * (0.5 * (w + fL0 / r.Dl0) + (qacc_smooth - r.aref_l0));
+          if (r.Dl1 > 0) cl += fL1 * (0.5 * (-w + fL1 / r.Dl1) + (-qacc_smooth - r.aref_l1));
+          if (r.own) cl += fE * (0.5 * ((w - r.ce * wo) + fE / r.De) + ((qacc_smooth - r.ce * so) - r.aref_e));
+          if (env_sum(cl) > 0) { fF = fL0 = fL1 = fE = 0; }
+          else acc = qacc_smooth + w;
+        }
+        const unsigned actF = (unsigned)(__ballot(r.Df > 0) >> base), act0 = (unsigned)(__ballot(r.Dl0 > 0) >> base),
+                       act1 = (unsigned)(__ballot(r.Dl1 > 0) >> base), actE = (unsigned)(__ballot(r.own) >> base);
+        int iter = 0;
+        while (iter < m.iterations) {
+          double improvement = 0;
+          for (int q = 0; q < t.npgs; q++) {
+            const int ent = t.pgs_order[q], ol = ent & 0xff, kind = ent >> 8;
+            const unsigned act = kind == 0 ? actE : kind == 1 ? actF : kind == 2 ? act0 : act1;
+            if (!((act >> ol) & 1)) continue;  // env-uniform
+            const double ao = kind == 0 ? bperm(acc, eq_other_sa) : 0.0;  // kind is uniform
+            double delta = 0;
+            if (l == ol) {
+              double D, aref, old, ARii, ja;
+              if (kind == 0) { D = r.De; aref = r.aref_e; old = fE; ARii = ARe; ja = acc - r.ce * ao; }
+              else if (kind == 1) { D = r.Df; aref = r.aref_f; old = fF; ARii = ARf; ja = acc; }
+              else if (kind == 2) { D = r.Dl0; aref = r.aref_l0; old = fL0; ARii = AR0; ja = acc; }
+              else { D = r.Dl1; aref = r.aref_l1; old = fL1; ARii = AR1; ja = -acc; }
+              const double res = ja - aref + old / D;
+              double f = old - res / ARii;
+              if (kind == 1) f = f < -r.fl ? -r.fl : (f > r.fl ? r.fl : f);
+              else if (kind >= 2) { if (f < 0) f = 0; }
+              delta = f - old;
+              double change = 0.5 * delta * delta * ARii + delta * res;
+              if (change > 1e-10) { f = old; delta = 0; change = 0; }
+              if (kind == 0) fE = f; else if (kind == 1) fF = f; else if (kind == 2) fL0 = f; else fL1 = f;
+              improvement -= change;
+            }
+            const int osa = (base + ol) * 4;
+            const double dl = bperm(delta, osa);
+            // (M^-1 J_r^T)_l: column ol of M^-1 (sign for the upper limit, minus ce * the other dof's column for an equality)
+            double wl = Mrow[ol];
+            if (kind == 3) wl = -wl;
+            if (kind == 0) {
+              const int ok = __builtin_amdgcn_ds_bpermute(osa, ko);
+              const double ce = bperm(r.ce, osa);
+              wl -= ce * Mrow[ok];
+            }
+            if (has_dof && dl != 0) acc += dl * wl;
+          }
+          iter++;
+          if (env_sum(improvement) * scale < m.tolerance) break;
+        }
+        solver_iter = iter;
+        frc[0] = fF; frc[1] = fL0; frc[2] = fL1; frc[3] = fE;
+        qfrc_constraint = jtf();
+        qacc = qacc_smooth + tp_solve(c, LM.R, LM.dinv, qfrc_constraint);
+        if (!has_dof) qacc = 0;
+        qacc_ws = qacc;
       } else {
         TpSol s;
 #pragma unroll

@@ -580,6 +580,39 @@ def test_pgs_matches_oracle(hand_model, contacts):
     assert np.isfinite(sim.data.qpos.cpu().numpy()).all()
 
 
+def test_pgs_step_tree_parallel(hand_model, monkeypatch):
+    """bs_step with solver=PGS, contact-free, runs in the tree-parallel kernel (k_tp_pgs: M^-1 in
+    LDS, sweep in efc order): against the oracle and against the serial kernels, warm starts included."""
+    import torch
+    from mujoco_amd import BatchSim, workload
+    from oracle import OracleSim
+    m = workload.contact_free(hand_model)
+    m.opt_solver = 0
+    E, n = 48, 6
+    q, v = workload.config2_state(m, E, seed=1239)
+    c = workload.config2_ctrl(m, E, seed=1239)
+    res = {}
+    for kern in ("tp", "serial"):
+        if kern == "serial":
+            monkeypatch.setenv("BS_KERNEL", "serial")
+        sim = BatchSim(m, n_envs=E)
+        sim.data.qpos.copy_(torch.as_tensor(q)); sim.data.ctrl.copy_(torch.as_tensor(c))
+        sim.step(n); sim.sync()
+        res[kern] = [getattr(sim.data, f).cpu().numpy().copy() for f in ("qpos", "qvel", "qacc", "solver_iter")]
+        del sim
+    monkeypatch.delenv("BS_KERNEL")
+    for a, b in zip(res["tp"][:3], res["serial"][:3]):
+        assert np.abs(a - b).max() <= 1e-7 * max(1.0, np.abs(b).max())
+    assert np.abs(res["tp"][3].astype(int) - res["serial"][3].astype(int)).max() <= 1
+    for e in range(0, E, 5):
+        s = OracleSim(m)
+        s.qpos[:] = q[e]; s.ctrl[:] = c[e]
+        s.step(n)
+        assert np.abs(res["tp"][0][e] - s.qpos).max() < 1e-8
+        assert np.abs(res["tp"][1][e] - s.qvel).max() < 1e-7 * max(1.0, np.abs(s.qvel).max())
+        assert np.abs(res["tp"][2][e] - s.qacc).max() < 1e-6 * max(1.0, np.abs(s.qacc).max())
+
+
 def test_mixed_model_batch(hand_model):
     """BASELINE.json configs[3] shape: several models in one batch, environments sorted by model,
     one bs_step for all.  Three variants of the hand (contact-free Newton, self-collision Newton,
