@@ -198,14 +198,10 @@ static void build_tp(bs_model* m) {
       dat(TPD_EQ_DIAG, b) = iw + s.dof_invweight0[m->eq_dof2[r]];
     }
   }
-  // PGS sweep order = efc order: equalities, frictionloss rows, limits (lower, upper per joint)
+  // PGS sweep order = efc order: equalities (owner lanes listed here), then frictionloss rows and limits in
+  // dof order, which is the lane order (bodies and dofs are both numbered depth-first)
   m->tp_pgs.clear();
-  for (size_t r = 0; r < m->eq_dof1.size(); r++) m->tp_pgs.push_back(s.dof_bodyid[m->eq_dof1[r]] | (0 << 8));
-  for (size_t k = 0; k < m->fric_dof.size(); k++) m->tp_pgs.push_back(s.dof_bodyid[m->fric_dof[k]] | (1 << 8));
-  for (size_t k = 0; k < m->lim_jnt.size(); k++) {
-    m->tp_pgs.push_back(s.jnt_bodyid[m->lim_jnt[k]] | (2 << 8));
-    m->tp_pgs.push_back(s.jnt_bodyid[m->lim_jnt[k]] | (3 << 8));
-  }
+  for (size_t r = 0; r < m->eq_dof1.size(); r++) m->tp_pgs.push_back(s.dof_bodyid[m->eq_dof1[r]]);
   m->tp.npgs = (int)m->tp_pgs.size();
   m->tp.maxdepth = maxdepth; m->tp.maxdd = maxdd; m->tp.nroots = nroots;
   int mind = maxdepth;
@@ -680,7 +676,7 @@ __global__ __launch_bounds__(64, 2) void k_tp_cg(DevModel m, TpModel t, DevData 
 // same with solver = PGS (contact-free, Euler): M^-1 of the two environments lives in LDS
 __global__ __launch_bounds__(64, 2) void k_tp_pgs(DevModel m, TpModel t, DevData d, int nsteps, int mode, int dump) {
   __shared__ int tbl[TPL_TOTAL * 64];
-  __shared__ double minv[2 * TP_LPE * TP_MINV_STRIDE];
+  extern __shared__ double minv[];  // 2 x nbody x tp_minv_stride(nbody)
   const TpShared sh = {tbl, nullptr, nullptr, nullptr, nullptr, minv};
   ColModel cm;
   ColData cd;
@@ -1034,7 +1030,8 @@ static void launch_step(bs_sim* s, int n_steps) {
   }
   if (s->use_tp)
     hipLaunchKernelGGL(s->dm.solver == 0 ? k_tp_pgs : s->dm.solver == 1 ? k_tp_cg : s->dm.integrator == 1 ? k_tp_rk4 : k_tp,
-                       grid_tp(s), dim3(64), 0, s->stream, s->dm, s->tp, s->dd,
+                       grid_tp(s), dim3(64),
+                       s->dm.solver == 0 ? (size_t)2 * s->dm.nbody * tp_minv_stride(s->dm.nbody) * sizeof(double) : 0, s->stream, s->dm, s->tp, s->dd,
                        n_steps, 0, 1);
   else
     hipLaunchKernelGGL(k_step, grid_for(s), dim3(BS_BLOCK), 0, s->stream, s->dm, s->dd, n_steps);

@@ -59,8 +59,8 @@ struct TpModel {
   int maxdepth, maxdd, nroots;
   int jump_rounds;  // ceil(log2(maxdepth)): pointer-jumping rounds that reach the world from every body
   int fold_minlvl;  // leaves-to-root folds (crb, rne forces) stop here: no body above this depth carries a dof
-  // PGS sweep order (mj_solPGS visits the rows in efc order: equality, frictionloss, limits): one entry
-  // per possible row, lane | kind << 8 with kind 0 equality (owner lane), 1 frictionloss, 2 lower, 3 upper limit
+  // PGS sweep order (mj_solPGS visits the rows in efc order: equality, frictionloss, limits): owner lanes
+  // of the equality rows in equality order; the other rows follow the dof order, which is the lane order
   const int* pgs_order;
   int npgs;
   int roots[4];
@@ -170,7 +170,8 @@ typedef int __attribute__((address_space(3))) * tp_lds_i;
 #define TPC_NTRI ((TPC_HTRI + TP_LPE - 1) / TP_LPE)
 enum { CG_POS = 0, CG_FRAME = 3, CG_DIST = 12, CG_PAIR = 13, CG_D = 14, CG_MASK = 15, CG_MU = 16 };  // PAIR: pair id | active rows
 struct TpShared { int* tbl; double* H; double* cg; double* U; double* park; double* minv; };  // park: [TP_MAXD + 1][64] or null
-#define TP_MINV_STRIDE 33  // doubles per row of the per-environment M^-1 in LDS (odd: conflict-free columns)
+// per-environment M^-1 in LDS (PGS): nbody rows of (nbody | 1) doubles (odd stride: conflict-free columns)
+__host__ __device__ inline int tp_minv_stride(int nbody) { return nbody | 1; }
 // the two environments of a wavefront diverge, so LDS hand-offs between lanes of one environment
 // are ordered with a fence + scheduling barrier instead of s_barrier (LDS is in-order per wave)
 __device__ __forceinline__ void tp_wave_sync() {
@@ -343,6 +344,58 @@ __device__ TP_HELPER_ATTR double tp_solve(TpCtx c, TpRow Rin, double dinv, doubl
     }
   }
   return x;
+}
+
+// N right-hand sides at once: the level sweeps and their cross-lane round trips are shared
+template <int N>
+__device__ TP_HELPER_ATTR void tp_solve_n(TpCtx c, TpRow Rin, double dinv, double (&x)[N]) {
+  const double* R = Rin.r;
+  double W[N][TP_MAXD];
+#pragma unroll
+  for (int n = 0; n < N; n++)
+#pragma unroll
+    for (int a = 0; a < TP_MAXD; a++) W[n][a] = 0;
+#pragma unroll
+  for (int D = TP_MAXD; D >= 2; D--) {
+    if (D > c.maxdd) continue;
+    const bool is = c.dd == D, par = c.dd == D - 1;
+    double T[N][TP_MAXD];
+#pragma unroll
+    for (int n = 0; n < N; n++)
+#pragma unroll
+      for (int a = 1; a < TP_MAXD; a++)
+        if (a < D) T[n][a] = is ? R[a] * x[n] + W[n][a] : 0.0;
+    for (int ch = 0; ch < c.nchild[D]; ch++) {
+      const int src = c.tbl[(TPL_DCHILD + ch) * 64 + threadIdx.x];
+      const int sa = par && src >= 0 ? src : c.zero_sa;
+#pragma unroll
+      for (int a = 1; a < TP_MAXD; a++) {
+        if (a >= D) continue;
+#pragma unroll
+        for (int n = 0; n < N; n++) {
+          const double v = bperm(T[n][a], sa);
+          if (a == 1) x[n] -= v;
+          else W[n][a - 1] += v;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int n = 0; n < N; n++) x[n] *= dinv;
+#pragma unroll
+  for (int D = 2; D <= TP_MAXD; D++) {
+    if (D > c.maxdd) continue;
+    const bool is = c.dd == D;
+#pragma unroll
+    for (int a = 1; a < TP_MAXD; a++) {
+      if (a >= D) continue;
+#pragma unroll
+      for (int n = 0; n < N; n++) {
+        const double xa = bperm(x[n], c.anc_sa[a]);
+        if (is) x[n] -= R[a] * xa;
+      }
+    }
+  }
 }
 
 // res = M v with the distributed sparse rows (mj_mulM)
@@ -1332,16 +1385,28 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
         qacc = qacc_smooth; qacc_ws = qacc_smooth; solver_iter = 0;
       } else if constexpr (PGS) {
         // ---- A11 mj_solPGS (same arithmetic as physics_contact.h::stage_pgs, contact-free)
-        const tp_lds_d Minv = (tp_lds_d)sh.minv + (size_t)(tid / TP_LPE) * TP_LPE * TP_MINV_STRIDE;
-        const tp_lds_d Mrow = Minv + l * TP_MINV_STRIDE;
+        const int mstride = tp_minv_stride(m.nbody);
+        const tp_lds_d Minv = (tp_lds_d)sh.minv + (size_t)(tid / TP_LPE) * m.nbody * mstride;
+        const tp_lds_d Mrow = Minv + (l < m.nbody ? l : 0) * mstride;  // lanes beyond the bodies never write
         const unsigned dofs = (unsigned)(__ballot(has_dof) >> base);
-        for (int jl = 1; jl < m.nbody; jl++) {  // M^-1 e_j for every dof (lane jl), one solve each
-          if (!((dofs >> jl) & 1)) continue;
-          Mrow[jl] = tp_solve(c, LM.R, LM.dinv, l == jl ? 1.0 : 0.0);
+        for (unsigned left = dofs; left;) {  // M^-1 e_j for every dof (lane j), three columns per sweep
+          int col[3];
+          double x[3];
+#pragma unroll
+          for (int n = 0; n < 3; n++) {
+            col[n] = left ? __builtin_ctz(left) : -1;
+            if (left) left &= left - 1;
+            x[n] = l == col[n] ? 1.0 : 0.0;
+          }
+          tp_solve_n<3>(c, LM.R, LM.dinv, x);
+#pragma unroll
+          for (int n = 0; n < 3; n++)
+            if (col[n] >= 0 && l < m.nbody) Mrow[col[n]] = x[n];
         }
         tp_wave_sync();
+        TPC_T(20)
         const int ko = (eq_other_sa >> 2) & (TP_LPE - 1);  // lane of the equality's other dof (own lane if none)
-        const tp_lds_d Orow = Minv + ko * TP_MINV_STRIDE;
+        const tp_lds_d Orow = Minv + ko * mstride;
         // (M^-1 J_r^T)_l for the row kinds, J_r (M^-1 J_r^T) + 1/D on the owner lane
         const double mjj = has_dof ? Mrow[l] : 0.0;
         const double ARf = mjj + (r.Df > 0 ? 1.0 / r.Df : 0.0), AR0 = mjj + (r.Dl0 > 0 ? 1.0 / r.Dl0 : 0.0),
@@ -1375,45 +1440,63 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
         const unsigned actF = (unsigned)(__ballot(r.Df > 0) >> base), act0 = (unsigned)(__ballot(r.Dl0 > 0) >> base),
                        act1 = (unsigned)(__ballot(r.Dl1 > 0) >> base), actE = (unsigned)(__ballot(r.own) >> base);
         int iter = 0;
+        TPC_T(21)
+        // reciprocals of D and of the diagonal of A + R once per step (the sweep is a latency chain)
+        const double iDf = r.Df > 0 ? 1.0 / r.Df : 0.0, iD0 = r.Dl0 > 0 ? 1.0 / r.Dl0 : 0.0, iD1 = r.Dl1 > 0 ? 1.0 / r.Dl1 : 0.0,
+                     iDe = r.own ? 1.0 / r.De : 0.0;
+        const double iARf = 1.0 / ARf, iAR0 = 1.0 / AR0, iAR1 = 1.0 / AR1, iARe = 1.0 / ARe;
+        // one row: the owner lane ol projects its force, everybody applies the change.  kind is
+        // uniform over the wavefront, ol over the environment.
+        auto row = [&](int kind, int ol, double& improvement) {
+          const double ao = kind == 0 ? bperm(acc, eq_other_sa) : 0.0;
+          double delta = 0;
+          if (l == ol) {
+            double iD, aref, old, ARii, iAR, ja;
+            if (kind == 0) { iD = iDe; aref = r.aref_e; old = fE; ARii = ARe; iAR = iARe; ja = acc - r.ce * ao; }
+            else if (kind == 1) { iD = iDf; aref = r.aref_f; old = fF; ARii = ARf; iAR = iARf; ja = acc; }
+            else if (kind == 2) { iD = iD0; aref = r.aref_l0; old = fL0; ARii = AR0; iAR = iAR0; ja = acc; }
+            else { iD = iD1; aref = r.aref_l1; old = fL1; ARii = AR1; iAR = iAR1; ja = -acc; }
+            const double res = ja - aref + old * iD;
+            double f = old - res * iAR;
+            if (kind == 1) f = f < -r.fl ? -r.fl : (f > r.fl ? r.fl : f);
+            else if (kind >= 2) { if (f < 0) f = 0; }
+            delta = f - old;
+            double change = 0.5 * delta * delta * ARii + delta * res;
+            if (change > 1e-10) { f = old; delta = 0; change = 0; }
+            if (kind == 0) fE = f; else if (kind == 1) fF = f; else if (kind == 2) fL0 = f; else fL1 = f;
+            improvement -= change;
+          }
+          const int osa = (base + ol) * 4;
+          const double dl = bperm(delta, osa);
+          // (M^-1 J_r^T)_l: column ol of M^-1 (sign for the upper limit, minus ce * the other dof's column for an equality)
+          double wl = Mrow[ol];
+          if (kind == 3) wl = -wl;
+          if (kind == 0) {
+            const int ok = __builtin_amdgcn_ds_bpermute(osa, ko);
+            const double ce = bperm(r.ce, osa);
+            wl -= ce * Mrow[ok];
+          }
+          if (has_dof) acc += dl * wl;
+        };
+        const unsigned actL = act0 | act1;
         while (iter < m.iterations) {
           double improvement = 0;
+          // efc order: equalities (host schedule: their owners are in equality order), frictionloss rows
+          // and limits in dof order = lane order, lower before upper limit of a joint
           for (int q = 0; q < t.npgs; q++) {
-            const int ent = t.pgs_order[q], ol = ent & 0xff, kind = ent >> 8;
-            const unsigned act = kind == 0 ? actE : kind == 1 ? actF : kind == 2 ? act0 : act1;
-            if (!((act >> ol) & 1)) continue;  // env-uniform
-            const double ao = kind == 0 ? bperm(acc, eq_other_sa) : 0.0;  // kind is uniform
-            double delta = 0;
-            if (l == ol) {
-              double D, aref, old, ARii, ja;
-              if (kind == 0) { D = r.De; aref = r.aref_e; old = fE; ARii = ARe; ja = acc - r.ce * ao; }
-              else if (kind == 1) { D = r.Df; aref = r.aref_f; old = fF; ARii = ARf; ja = acc; }
-              else if (kind == 2) { D = r.Dl0; aref = r.aref_l0; old = fL0; ARii = AR0; ja = acc; }
-              else { D = r.Dl1; aref = r.aref_l1; old = fL1; ARii = AR1; ja = -acc; }
-              const double res = ja - aref + old / D;
-              double f = old - res / ARii;
-              if (kind == 1) f = f < -r.fl ? -r.fl : (f > r.fl ? r.fl : f);
-              else if (kind >= 2) { if (f < 0) f = 0; }
-              delta = f - old;
-              double change = 0.5 * delta * delta * ARii + delta * res;
-              if (change > 1e-10) { f = old; delta = 0; change = 0; }
-              if (kind == 0) fE = f; else if (kind == 1) fF = f; else if (kind == 2) fL0 = f; else fL1 = f;
-              improvement -= change;
-            }
-            const int osa = (base + ol) * 4;
-            const double dl = bperm(delta, osa);
-            // (M^-1 J_r^T)_l: column ol of M^-1 (sign for the upper limit, minus ce * the other dof's column for an equality)
-            double wl = Mrow[ol];
-            if (kind == 3) wl = -wl;
-            if (kind == 0) {
-              const int ok = __builtin_amdgcn_ds_bpermute(osa, ko);
-              const double ce = bperm(r.ce, osa);
-              wl -= ce * Mrow[ok];
-            }
-            if (has_dof && dl != 0) acc += dl * wl;
+            const int ol = t.pgs_order[q];
+            if ((actE >> ol) & 1) row(0, ol, improvement);
+          }
+          for (unsigned mk = actF; mk; mk &= mk - 1) row(1, __builtin_ctz(mk), improvement);
+          for (unsigned mk = actL; mk; mk &= mk - 1) {
+            const int ol = __builtin_ctz(mk);
+            if ((act0 >> ol) & 1) row(2, ol, improvement);
+            if ((act1 >> ol) & 1) row(3, ol, improvement);
           }
           iter++;
           if (env_sum(improvement) * scale < m.tolerance) break;
         }
+        TPC_T(22)
         solver_iter = iter;
         frc[0] = fF; frc[1] = fL0; frc[2] = fL1; frc[3] = fE;
         qfrc_constraint = jtf();
@@ -1622,7 +1705,7 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
     if (tid == 0 && cd.stat)
       for (int q = 0; q < 24; q++) atomicAdd(cd.stat + 8 + q, tacc[q]);
   } else if (blockIdx.x == 7 && tid == 0) {
-    for (int q = 0; q < 20; q++) printf("sec %d %llu\n", q, tacc[q]);
+    for (int q = 0; q < 24; q++) printf("sec %d %llu\n", q, tacc[q]);
   }
 #endif
   if constexpr (CON) {
