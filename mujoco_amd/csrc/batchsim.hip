@@ -906,11 +906,14 @@ __global__ __launch_bounds__(BS_BLOCK) void k_c_dyn(DevModel m, ColModel cm, Dev
   }
 }
 
+#ifndef NL_THREADS
+#define NL_THREADS 64  // one wavefront per block measured best (3.21 / 3.25 / 3.30 ms per step for 64 / 128 / 256)
+#endif
 // narrowphase over the work list k_tp_col wrote: one lane per item whatever environment it belongs
 // to, so every wavefront but the last is full
-__global__ __launch_bounds__(NB_THREADS) void k_c_narrow_list(ColModel cm, DevData d, ColData c) {
+__global__ __launch_bounds__(NL_THREADS) void k_c_narrow_list(ColModel cm, DevData d, ColData c) {
   __shared__ unsigned pre[BS_NSUB + 1];
-  __shared__ MprState mpr[NB_THREADS];
+  __shared__ MprState mpr[NL_THREADS];
   const int tid = threadIdx.x;
   if (tid < BS_NSUB) {  // first wavefront: inclusive scan of the sub-list lengths
     unsigned v = (unsigned)c.stat[BS_STAT_ITEMS + d.range * BS_NSUB + tid];
@@ -926,7 +929,7 @@ __global__ __launch_bounds__(NB_THREADS) void k_c_narrow_list(ColModel cm, DevDa
   const int* items = c.items + col_items_base(d.env0, d.range, cm.maxcand);
   const long subcap = col_items_subcap(d.n_envs - d.env0, cm.maxcand);
   unsigned acc[2] = {0, 0};
-  for (unsigned i = blockIdx.x * NB_THREADS + tid; i < total; i += gridDim.x * NB_THREADS) {
+  for (unsigned i = blockIdx.x * NL_THREADS + tid; i < total; i += gridDim.x * NL_THREADS) {
     int lo = 0, hi = BS_NSUB;  // sub-list of item i: largest s with pre[s] <= i
     while (hi - lo > 1) {
       const int mid = (lo + hi) >> 1;
@@ -968,9 +971,9 @@ static void launch_tpc_pass(bs_sim* s, const DevData& dd, hipStream_t st, int mo
   if (s->narrow_ws || s->narrow_blocks) {
     launch_narrow(s, dd, st);
   } else {
-    size_t nb = ((size_t)(dd.n_envs - dd.env0) * s->cm.maxcand + NB_THREADS - 1) / NB_THREADS;
-    nb = nb < 1 ? 1 : nb > 8192 ? 8192 : nb;
-    hipLaunchKernelGGL(k_c_narrow_list, dim3((unsigned)nb), dim3(NB_THREADS), 0, st, s->cm, dd, s->cd);
+    size_t nb = ((size_t)(dd.n_envs - dd.env0) * s->cm.maxcand + NL_THREADS - 1) / NL_THREADS;
+    nb = nb < 1 ? 1 : nb > 16384 ? 16384 : nb;
+    hipLaunchKernelGGL(k_c_narrow_list, dim3((unsigned)nb), dim3(NL_THREADS), 0, st, s->cm, dd, s->cd);
   }
   const int ntri = s->dm.nbody * (s->dm.nbody + 1) / 2;
   const size_t lds = (size_t)(2 * ntri + 2 * TP_LPE * TPC_SLOT + 2 * TP_LPE * 3) * sizeof(double);
