@@ -174,8 +174,12 @@ struct TpShared { int* tbl; double* H; double* cg; double* U; double* park; doub
 __host__ __device__ inline int tp_minv_stride(int nbody) { return nbody | 1; }
 // the two environments of a wavefront diverge, so LDS hand-offs between lanes of one environment
 // are ordered with a fence + scheduling barrier instead of s_barrier (LDS is in-order per wave)
+// Every block of these kernels is ONE wavefront and the hardware executes a wavefront's LDS
+// instructions in order, so nothing has to be waited for: the fence (wavefront scope: no s_waitcnt,
+// in particular none for outstanding scratch traffic) and the scheduling barrier only keep the
+// compiler from moving LDS accesses across the hand-off.
 __device__ __forceinline__ void tp_wave_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
 }
 struct TpRow { double r[TP_MAXD]; };
