@@ -112,6 +112,38 @@ class BatchData:
         else:
             raise AttributeError(f"cannot set {name}")
 
+    # -- mujoco-py's by-name accessors (PyMjData.get_joint_qpos & co.); the leading axis is the
+    #    environment (absent for n_envs == 1, as everywhere in sim.data)
+    def _col(self, field, idx):
+        v = self._view(field)
+        return v[idx] if self._sim.n_envs == 1 else v[:, idx]
+
+    def get_joint_qpos(self, name):
+        return self._col("qpos", self._sim.model.get_joint_qpos_addr(name))
+
+    def get_joint_qvel(self, name):
+        return self._col("qvel", self._sim.model.get_joint_qvel_addr(name))
+
+    def set_joint_qpos(self, name, value):
+        import torch
+        self._col("qpos", self._sim.model.get_joint_qpos_addr(name)).copy_(torch.as_tensor(value))
+
+    def set_joint_qvel(self, name, value):
+        import torch
+        self._col("qvel", self._sim.model.get_joint_qvel_addr(name)).copy_(torch.as_tensor(value))
+
+    def get_body_xpos(self, name):
+        return self._col("xpos", self._sim.model.body_name2id(name))
+
+    def get_body_xquat(self, name):
+        return self._col("xquat", self._sim.model.body_name2id(name))
+
+    def get_body_xmat(self, name):
+        return self._col("xmat", self._sim.model.body_name2id(name)).unflatten(-1, (3, 3))
+
+    def get_geom_xpos(self, name):
+        return self._col("geom_xpos", self._sim.model.geom_name2id(name))
+
     def contacts(self, env=0, cap=64):
         """`sim.data.contact[i].geom1/geom2/dist` for one environment: list of (geom1, geom2, dist)."""
         g1 = (C.c_int32 * cap)()

@@ -844,3 +844,22 @@ def test_long_rollout_invariants(hand_model, contacts):
     assert np.maximum(m.jnt_range[:, 0] - qp, qp - m.jnt_range[:, 1]).max() < 0.05
     assert np.abs(qv).max() < 50.0
     assert abs(float(sim.data.time[0]) - periods * 50 * m.opt_timestep) < 1e-9
+
+
+def test_by_name_accessors(hand_model):
+    """mujoco-py's PyMjData helpers (get/set_joint_qpos, get_body_xpos, ...) over the batched views."""
+    import torch
+    from mujoco_amd import BatchSim, workload
+    m = workload.contact_free(hand_model)
+    jn, bn = m.joint_names[5], m.body_names[9]
+    sim = BatchSim(m, n_envs=3)
+    sim.data.set_joint_qpos(jn, torch.tensor([0.1, 0.2, 0.3], dtype=torch.float64))
+    sim.forward(); sim.sync()
+    assert torch.equal(sim.data.get_joint_qpos(jn).cpu(), torch.tensor([0.1, 0.2, 0.3], dtype=torch.float64))
+    assert torch.equal(sim.data.qpos[:, m.get_joint_qpos_addr(jn)], sim.data.get_joint_qpos(jn))
+    assert sim.data.get_body_xpos(bn).shape == (3, 3) and sim.data.get_body_xmat(bn).shape == (3, 3, 3)
+    assert torch.equal(sim.data.get_body_xpos(bn), sim.data.xpos[:, m.body_name2id(bn)])
+    one = BatchSim(m, n_envs=1)
+    one.data.set_joint_qvel(jn, 0.5)
+    assert float(one.data.get_joint_qvel(jn)) == 0.5 and one.data.get_body_xquat(bn).shape == (4,)
+    assert one.data.get_body_xmat(bn).shape == (3, 3)
