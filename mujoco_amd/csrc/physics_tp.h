@@ -905,6 +905,35 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
         for (int k = 0; k < 6; k++) cdof[k] = 0;
       }
       TPC_T(13)
+      // ---- A8 comVel + rne body forces first, so that their leaves-to-root fold shares the level loop
+      // (and its cross-lane round trips) with the crb fold of A3
+      double cvel[6], qfrc_bias, f[6];
+      {
+        // cvel = sum of cdof * qvel over the body's chain; cacc = -gravity + sum over the chain of
+        // (parent's cvel x cdof) * qvel: two chain sums and one parent fetch instead of one pass per level
+        double acc[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) cvel[k] = isb ? cdof[k] * qvel : 0.0;
+        tp_chain_sum<6>(cvel, par_sa, t.jump_rounds, isb);
+        {
+          double pv[6], cdd[6];
+#pragma unroll
+          for (int k = 0; k < 6; k++) pv[k] = bperm(cvel[k], par_sa);
+          cross_motion(cdd, pv, cdof);
+#pragma unroll
+          for (int k = 0; k < 6; k++) acc[k] = isb ? cdd[k] * qvel : 0.0;
+        }
+        tp_chain_sum<6>(acc, par_sa, t.jump_rounds, isb);
+        if (isb && !(m.disableflags & BS_DSBL_GRAVITY)) {
+          acc[3] -= m.gravity[0]; acc[4] -= m.gravity[1]; acc[5] -= m.gravity[2];
+        }
+        double t0[6], t1[6], t2[6];
+        mul_inert_vec(t0, cinert, acc);
+        mul_inert_vec(t1, cinert, cvel);
+        cross_force(t2, cvel, t1);
+#pragma unroll
+        for (int k = 0; k < 6; k++) f[k] = isb ? t0[k] + t2[k] : 0.0;
+      }
       // ---- A3 crb (children folded into parents, deepest level first) + mass-matrix rows
       TpRow Mr;
       {
@@ -918,8 +947,14 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
             const int sa = par && src >= 0 ? src : c.zero_sa;
 #pragma unroll
             for (int k = 0; k < 10; k++) crb[k] += bperm(crb[k], sa);
+#pragma unroll
+            for (int k = 0; k < 6; k++) f[k] += bperm(f[k], sa);
           }
         }
+        double s = 0;
+#pragma unroll
+        for (int k = 0; k < 6; k++) s += cdof[k] * f[k];
+        qfrc_bias = s;
         double buf[6];
         mul_inert_vec(buf, crb, cdof);
         double s0 = 0;
@@ -954,47 +989,6 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
         LM = tp_factor(c, Mr);
       }
       TPC_T(15)
-      // ---- A8 comVel + rne bias
-      double cvel[6], qfrc_bias;
-      {
-        // cvel = sum of cdof * qvel over the body's chain; cacc = -gravity + sum over the chain of
-        // (parent's cvel x cdof) * qvel: two chain sums and one parent fetch instead of one pass per level
-        double acc[6];
-#pragma unroll
-        for (int k = 0; k < 6; k++) cvel[k] = isb ? cdof[k] * qvel : 0.0;
-        tp_chain_sum<6>(cvel, par_sa, t.jump_rounds, isb);
-        {
-          double pv[6], cdd[6];
-#pragma unroll
-          for (int k = 0; k < 6; k++) pv[k] = bperm(cvel[k], par_sa);
-          cross_motion(cdd, pv, cdof);
-#pragma unroll
-          for (int k = 0; k < 6; k++) acc[k] = isb ? cdd[k] * qvel : 0.0;
-        }
-        tp_chain_sum<6>(acc, par_sa, t.jump_rounds, isb);
-        if (isb && !(m.disableflags & BS_DSBL_GRAVITY)) {
-          acc[3] -= m.gravity[0]; acc[4] -= m.gravity[1]; acc[5] -= m.gravity[2];
-        }
-        double t0[6], t1[6], t2[6], f[6];
-        mul_inert_vec(t0, cinert, acc);
-        mul_inert_vec(t1, cinert, cvel);
-        cross_force(t2, cvel, t1);
-#pragma unroll
-        for (int k = 0; k < 6; k++) f[k] = isb ? t0[k] + t2[k] : 0.0;
-        for (int lvl = t.maxdepth; lvl >= t.fold_minlvl; lvl--) {
-          const bool par = isb && depth == lvl - 1;
-          for (int ch = 0; ch < t.lvl_bchild[lvl]; ch++) {
-            const int src = tbl[(TPL_BCHILD + ch) * 64 + tid];
-            const int sa = par && src >= 0 ? src : c.zero_sa;
-#pragma unroll
-            for (int k = 0; k < 6; k++) f[k] += bperm(f[k], sa);
-          }
-        }
-        double s = 0;
-#pragma unroll
-        for (int k = 0; k < 6; k++) s += cdof[k] * f[k];
-        qfrc_bias = s;
-      }
       TPC_T(16)
       // ---- passive + A9 actuation + A10 smooth acceleration
       double qfrc_passive = 0, act_force = 0, qfrc_actuator = 0;
