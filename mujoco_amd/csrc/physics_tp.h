@@ -350,6 +350,57 @@ __device__ TP_HELPER_ATTR double tp_solve(TpCtx c, TpRow Rin, double dinv, doubl
   return x;
 }
 
+// tp_solve(R, dinv, x) and tp_mul_m(M, v) in one pass: the leaves-to-root sweeps of the two have the
+// same level loop, so the product rides along in the solve's cross-lane round trips
+__device__ TP_HELPER_ATTR double tp_solve_mulm(TpCtx c, TpRow Rin, double dinv, double x, TpRow Min, double v, double& mv) {
+  const double* R = Rin.r;
+  const double* Mr = Min.r;
+  double res = c.dd > 0 ? Mr[0] * v : 0.0;
+#pragma unroll
+  for (int a = 1; a < TP_MAXD; a++) {
+    if (a >= c.maxdd) continue;
+    const double va = bperm(v, c.anc_sa[a]);
+    if (a < c.dd) res += Mr[a] * va;
+  }
+  double W[TP_MAXD], V[TP_MAXD];
+#pragma unroll
+  for (int a = 0; a < TP_MAXD; a++) { W[a] = 0; V[a] = 0; }
+#pragma unroll
+  for (int D = TP_MAXD; D >= 2; D--) {
+    if (D > c.maxdd) continue;
+    const bool is = c.dd == D, par = c.dd == D - 1;
+    double T[TP_MAXD], U[TP_MAXD];
+#pragma unroll
+    for (int a = 1; a < TP_MAXD; a++)
+      if (a < D) { T[a] = is ? R[a] * x + W[a] : 0.0; U[a] = is ? Mr[a] * v + V[a] : 0.0; }
+    for (int ch = 0; ch < c.nchild[D]; ch++) {
+      const int src = c.tbl[(TPL_DCHILD + ch) * 64 + threadIdx.x];
+      const int sa = par && src >= 0 ? src : c.zero_sa;
+#pragma unroll
+      for (int a = 1; a < TP_MAXD; a++) {
+        if (a >= D) continue;
+        const double t = bperm(T[a], sa), u = bperm(U[a], sa);
+        if (a == 1) { x -= t; res += u; }
+        else { W[a - 1] += t; V[a - 1] += u; }
+      }
+    }
+  }
+  mv = res;
+  x *= dinv;
+#pragma unroll
+  for (int D = 2; D <= TP_MAXD; D++) {
+    if (D > c.maxdd) continue;
+    const bool is = c.dd == D;
+#pragma unroll
+    for (int a = 1; a < TP_MAXD; a++) {
+      if (a >= D) continue;
+      const double xa = bperm(x, c.anc_sa[a]);
+      if (is) x -= R[a] * xa;
+    }
+  }
+  return x;
+}
+
 // N right-hand sides at once: the level sweeps and their cross-lane round trips are shared
 template <int N>
 __device__ TP_HELPER_ATTR void tp_solve_n(TpCtx c, TpRow Rin, double dinv, double (&x)[N]) {
@@ -1011,7 +1062,11 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
         qfrc_actuator = gear * f;
       }
       const double qfrc_smooth = has_dof ? qfrc_passive - qfrc_bias + qfrc_applied + qfrc_actuator : 0.0;
-      const double qacc_smooth = tp_solve(c, LM.R, LM.dinv, qfrc_smooth);
+      // M * qacc_warmstart (needed by the primal solvers' warm start) rides along in the solve's sweeps
+      double Ma_ws = 0;
+      const bool warm = !PGS && !(m.disableflags & BS_DSBL_WARMSTART) && !(m.disableflags & BS_DSBL_CONSTRAINT);
+      const double qacc_smooth = warm ? tp_solve_mulm(c, LM.R, LM.dinv, qfrc_smooth, Mr, qacc_ws, Ma_ws)
+                                      : tp_solve(c, LM.R, LM.dinv, qfrc_smooth);
       const bool dump_now = stage == 0 && step == nsteps - 1 && env_ok && dump >= 1;
       if (dump_now) {
         // outputs of the step's mj_forward, stored as soon as they exist so they are not kept
@@ -1518,9 +1573,7 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
         // warm start: previous acceleration only if cheaper than the unconstrained one
         // (M qacc_smooth == qfrc_smooth, so its Gauss term vanishes and Ma is known)
         bool use_smooth = true;
-        double Ma_ws = 0;
         if (!(m.disableflags & BS_DSBL_WARMSTART)) {
-          Ma_ws = tp_mul_m(c, Mr, qacc_ws);
           double jf, jl0, jl1, je, cjt[4] = {0, 0, 0, 0};
           residual(qacc_ws, 1.0, jf, jl0, jl1, je, cjt);
           double cl = tp_rows_cost<false>(r, jf, jl0, jl1, je, nullptr) +
