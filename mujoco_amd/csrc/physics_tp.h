@@ -251,6 +251,72 @@ __device__ TP_HELPER_ATTR TpFac tp_factor(TpCtx c, TpRow Rin) {
   return out;
 }
 
+// tp_factor followed by tp_solve with the same matrix, in one leaves-to-root pass: when the rows of
+// level D are final, their part of the forward substitution is sent up in the same exchange
+__device__ TP_HELPER_ATTR double tp_factor_solve(TpCtx c, TpRow Rin, double x) {
+  double* R = Rin.r;
+  double A[TP_NPAIR], W[TP_MAXD];
+#pragma unroll
+  for (int k = 0; k < TP_NPAIR; k++) A[k] = 0;
+#pragma unroll
+  for (int a = 0; a < TP_MAXD; a++) W[a] = 0;
+  double dinv = 1.0;
+#pragma unroll
+  for (int D = TP_MAXD; D >= 1; D--) {
+    if (D > c.maxdd) continue;
+    const bool is = c.dd == D;
+    double T[TP_NPAIR], S[TP_MAXD];
+    const double r0 = is ? R[0] : 1.0;
+    const double ir0 = 1.0 / r0;
+#pragma unroll
+    for (int a = 1; a < TP_MAXD; a++) {
+      if (a >= D) continue;
+      const double tmp = R[a] * ir0;
+#pragma unroll
+      for (int b = a; b < TP_MAXD; b++) {
+        if (b >= D) continue;
+        T[pair_idx(a, b)] = is ? tmp * R[b] + A[pair_idx(a, b)] : 0.0;
+      }
+      if (is) R[a] = tmp;
+      S[a] = is ? tmp * x + W[a] : 0.0;
+    }
+    if (is) dinv = ir0;
+    if (D == 1) break;
+    const bool par = c.dd == D - 1;
+    for (int ch = 0; ch < c.nchild[D]; ch++) {
+      const int src = c.tbl[(TPL_DCHILD + ch) * 64 + threadIdx.x];
+      const int sa = par && src >= 0 ? src : c.zero_sa;
+#pragma unroll
+      for (int a = 1; a < TP_MAXD; a++) {
+        if (a >= D) continue;
+        const double sv = bperm(S[a], sa);
+        if (a == 1) x -= sv;
+        else W[a - 1] += sv;
+#pragma unroll
+        for (int b = a; b < TP_MAXD; b++) {
+          if (b >= D) continue;
+          const double v = bperm(T[pair_idx(a, b)], sa);
+          if (a == 1) R[b - 1] -= v;
+          else A[pair_idx(a - 1, b - 1)] += v;
+        }
+      }
+    }
+  }
+  x *= dinv;
+#pragma unroll
+  for (int D = 2; D <= TP_MAXD; D++) {
+    if (D > c.maxdd) continue;
+    const bool is = c.dd == D;
+#pragma unroll
+    for (int a = 1; a < TP_MAXD; a++) {
+      if (a >= D) continue;
+      const double xa = bperm(x, c.anc_sa[a]);
+      if (is) x -= R[a] * xa;
+    }
+  }
+  return x;
+}
+
 // two factorisations with the same sparsity at once (M and M + h * damping): the level loop and its
 // cross-lane round trips are shared, so the second factor costs issue slots, not latency
 __device__ TP_HELPER_ATTR void tp_factor2(TpCtx c, TpRow R0in, TpRow R1in, TpFac& out0, TpFac& out1) {
@@ -1650,8 +1716,8 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
             const double x = con_newton_dir(Hr, s.cj, has_dof ? s.grad : 0.0);
             s.search = has_dof ? -x : 0.0;
           } else {
-            const TpFac LH = tp_factor(c, Hr);
-            s.search = has_dof ? -tp_solve(c, LH.R, LH.dinv, s.grad) : 0.0;
+            const double x = tp_factor_solve(c, Hr, s.grad);
+            s.search = has_dof ? -x : 0.0;
           }
           }
           TPC_T(9)
