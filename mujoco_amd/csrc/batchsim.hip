@@ -191,6 +191,16 @@ static void build_tp(bs_model* m) {
       kb_from_solref(hm, s.jnt_solref + 2 * j, s.jnt_solimp + 5 * j, K, B);
       dat(TPD_LIM_K, b) = K; dat(TPD_LIM_B, b) = B;
     }
+    dat(TPD_STIFF, b) = s.jnt_stiffness[j]; dat(TPD_SPRING, b) = s.qpos_spring[j];
+    const int u = act_of[j];
+    if (u >= 0) {
+      const bool cl = s.actuator_ctrllimited[u] && !(s.disableflags & BS_DSBL_CLAMPCTRL), fl = s.actuator_forcelimited[u];
+      dat(TPD_ACT_GEAR, b) = s.actuator_gear[u]; dat(TPD_ACT_GAIN, b) = s.actuator_gainprm[3 * u];
+      dat(TPD_ACT_B0, b) = s.actuator_biasprm[3 * u]; dat(TPD_ACT_B1, b) = s.actuator_biasprm[3 * u + 1];
+      dat(TPD_ACT_B2, b) = s.actuator_biasprm[3 * u + 2];
+      dat(TPD_ACT_CLO, b) = cl ? s.actuator_ctrlrange[2 * u] : -1e300; dat(TPD_ACT_CHI, b) = cl ? s.actuator_ctrlrange[2 * u + 1] : 1e300;
+      dat(TPD_ACT_FLO, b) = fl ? s.actuator_forcerange[2 * u] : -1e300; dat(TPD_ACT_FHI, b) = fl ? s.actuator_forcerange[2 * u + 1] : 1e300;
+    }
     const int r = at(TPI_EQ_OWN, b);
     if (r >= 0) {
       kb_from_solref(hm, m->eq_solref.data() + 2 * r, m->eq_solimp.data() + 5 * r, K, B);

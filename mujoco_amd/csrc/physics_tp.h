@@ -50,6 +50,9 @@ enum {
   TPD_FRIC_D, TPD_FRIC_RF, TPD_FRIC_FL, TPD_FRIC_B,  // D = 1/R (0: no row), R * frictionloss, frictionloss, B
   TPD_LIM_K, TPD_LIM_B,                            // K < 0: joint not limited
   TPD_EQ_K, TPD_EQ_B, TPD_EQ_DIAG,                 // of the equality this lane owns
+  // passive force and actuator of the lane's joint: limits that are off are +-1e300, so the clamps are unconditional
+  TPD_STIFF, TPD_SPRING, TPD_ACT_GEAR, TPD_ACT_GAIN, TPD_ACT_B0, TPD_ACT_B1, TPD_ACT_B2,
+  TPD_ACT_CLO, TPD_ACT_CHI, TPD_ACT_FLO, TPD_ACT_FHI,
   TPD_TOTAL
 };
 
@@ -725,7 +728,7 @@ __device__ __forceinline__ void tp_collide_prep(const DevModel& m, const TpModel
   const int self_sa = tid * 4;
   const int pv = t.lane[TPI_PARENT * TP_LPE + l];
   const int par_sa = pv >= 0 ? (base + pv) * 4 : self_sa;
-  const int depth = t.lane[TPI_DEPTH * TP_LPE + l], jnt = t.lane[TPI_JNT * TP_LPE + l];
+  const int jnt = t.lane[TPI_JNT * TP_LPE + l];
   const bool has_dof = jnt >= 0, isb = l < m.nbody && l > 0;
   const int b = l < m.nbody ? l : 0, j = has_dof ? jnt : 0;
   const V3 bpos = ld3(m.body_pos + 3 * b), jpos = ld3(m.jnt_pos + 3 * j), jax = ld3(m.jnt_axis + 3 * j);
@@ -1109,23 +1112,20 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
       TPC_T(16)
       // ---- passive + A9 actuation + A10 smooth acceleration
       double qfrc_passive = 0, act_force = 0, qfrc_actuator = 0;
-      if (has_dof && !(m.disableflags & BS_DSBL_PASSIVE))
-        qfrc_passive = -m.jnt_stiffness[j] * (qpos - m.qpos_spring[j]) - damping * qvel;
-      if (act >= 0 && !(m.disableflags & BS_DSBL_ACTUATION)) {
-        const double gear = m.actuator_gear[act];
-        double cc = ctrl;
-        if (m.actuator_ctrllimited[act] && !(m.disableflags & BS_DSBL_CLAMPCTRL)) {
-          cc = fmax(cc, m.actuator_ctrlrange[2 * act]);
-          cc = fmin(cc, m.actuator_ctrlrange[2 * act + 1]);
+      {
+        // joint and actuator constants from the per-lane table: one round of loads, no dependent branches
+        const double* pc = t.lane_d + l;
+        if (has_dof && !(m.disableflags & BS_DSBL_PASSIVE))
+          qfrc_passive = -pc[TPD_STIFF * TP_LPE] * (qpos - pc[TPD_SPRING * TP_LPE]) - damping * qvel;
+        if (act >= 0 && !(m.disableflags & BS_DSBL_ACTUATION)) {
+          const double gear = pc[TPD_ACT_GEAR * TP_LPE];
+          const double cc = fmin(fmax(ctrl, pc[TPD_ACT_CLO * TP_LPE]), pc[TPD_ACT_CHI * TP_LPE]);
+          double f = pc[TPD_ACT_GAIN * TP_LPE] * cc + pc[TPD_ACT_B0 * TP_LPE] + pc[TPD_ACT_B1 * TP_LPE] * (gear * qpos) +
+                     pc[TPD_ACT_B2 * TP_LPE] * (gear * qvel);
+          f = fmin(fmax(f, pc[TPD_ACT_FLO * TP_LPE]), pc[TPD_ACT_FHI * TP_LPE]);
+          act_force = f;
+          qfrc_actuator = gear * f;
         }
-        const double* bp = m.actuator_biasprm + 3 * act;
-        double f = m.actuator_gainprm[3 * act] * cc + bp[0] + bp[1] * (gear * qpos) + bp[2] * (gear * qvel);
-        if (m.actuator_forcelimited[act]) {
-          f = fmax(f, m.actuator_forcerange[2 * act]);
-          f = fmin(f, m.actuator_forcerange[2 * act + 1]);
-        }
-        act_force = f;
-        qfrc_actuator = gear * f;
       }
       const double qfrc_smooth = has_dof ? qfrc_passive - qfrc_bias + qfrc_applied + qfrc_actuator : 0.0;
       // M * qacc_warmstart (needed by the primal solvers' warm start) rides along in the solve's sweeps
