@@ -1,5 +1,5 @@
 """Turns the rocprofv3 outputs under gpurun_out/ (kernel-trace --stats runs and separate --pmc passes
-of `bench.py` and `bench.py --contacts --envs 65536`, see profiles/README.md for the commands) into
+of `bench.py` and `bench.py --contacts --envs 65536`, the commands are in profiles/collect.sh, see profiles/README.md) into
 the committed summaries: profiles/r01_*_kernel_stats.csv (verbatim copies) and r01_pmc_summary.json
 (per-launch averages per kernel)."""
 import collections
