@@ -863,3 +863,33 @@ def test_by_name_accessors(hand_model):
     one.data.set_joint_qvel(jn, 0.5)
     assert float(one.data.get_joint_qvel(jn)) == 0.5 and one.data.get_body_xquat(bn).shape == (4,)
     assert one.data.get_body_xmat(bn).shape == (3, 3)
+
+
+@pytest.mark.parametrize("kernel", ["tp", "serial"])
+def test_nan_guard_with_contacts(hand_model, kernel, monkeypatch):
+    """mj_checkPos on the contact path (k_tp_col treats the bad state as reset, k_tpc resets it): the
+    poisoned environment is reset and flagged, its neighbours are bit-for-bit what they are without it."""
+    import torch
+    from mujoco_amd import BatchSim, workload
+    if kernel == "serial":
+        monkeypatch.setenv("BS_KERNEL", "serial")
+    m = _contact_model(hand_model)
+    E = 66
+    q, v = workload.config2_state(m, E, seed=31)
+    c = workload.config2_ctrl(m, E, seed=31)
+    out = []
+    for poison in (False, True):
+        sim = BatchSim(m, n_envs=E)
+        sim.data.qpos.copy_(torch.as_tensor(q)); sim.data.ctrl.copy_(torch.as_tensor(c))
+        sim.step(3)
+        if poison:
+            sim.data.qpos[3, 7] = float("nan")
+            sim.data.qvel[65, 2] = float("inf")
+        sim.step(3); sim.sync()
+        out.append((sim.data.qpos.cpu().numpy().copy(), sim.data.warning.cpu().numpy().copy(), sim.data.time.cpu().numpy().copy()))
+    (q0, w0, t0), (q1, w1, t1) = out
+    assert np.isfinite(q1).all()
+    assert w1[3] & 1 and w1[65] & 2 and (w1[[0, 1, 2, 4, 64]] == 0).all() and (w0 == 0).all()
+    keep = np.ones(E, bool); keep[[3, 65]] = False
+    assert np.array_equal(q0[keep], q1[keep])
+    assert abs(t1[3] - 3 * m.opt_timestep) < 1e-12 and abs(t1[0] - 6 * m.opt_timestep) < 1e-12  # reset restarts the clock
