@@ -692,6 +692,22 @@ __global__ __launch_bounds__(64, 2) void k_tp_pgs(DevModel m, TpModel t, DevData
   ColData cd;
   tp_run<false, false, false, false, true>(m, t, d, nsteps, mode, dump, sh, cm, cd);
 }
+// RK4 with CG / PGS
+__global__ __launch_bounds__(64, 2) void k_tp_rk4_cg(DevModel m, TpModel t, DevData d, int nsteps, int mode, int dump) {
+  __shared__ int tbl[TPL_TOTAL * 64];
+  const TpShared sh = {tbl, nullptr, nullptr, nullptr, nullptr};
+  ColModel cm;
+  ColData cd;
+  tp_run<false, false, true, true>(m, t, d, nsteps, mode, dump, sh, cm, cd);
+}
+__global__ __launch_bounds__(64, 2) void k_tp_rk4_pgs(DevModel m, TpModel t, DevData d, int nsteps, int mode, int dump) {
+  __shared__ int tbl[TPL_TOTAL * 64];
+  extern __shared__ double minv[];
+  const TpShared sh = {tbl, nullptr, nullptr, nullptr, nullptr, minv};
+  ColModel cm;
+  ColData cd;
+  tp_run<false, false, true, false, true>(m, t, d, nsteps, mode, dump, sh, cm, cd);
+}
 // same with the RK4 integrator (three extra forward passes per step)
 __global__ __launch_bounds__(64, 2) void k_tp_rk4(DevModel m, TpModel t, DevData d, int nsteps, int mode, int dump) {
   __shared__ int tbl[TPL_TOTAL * 64];
@@ -1041,13 +1057,15 @@ static void launch_step(bs_sim* s, int n_steps) {
     for (int k = 0; k < n_steps; k++) launch_contact_pass(s, 1, 1, k == n_steps - 1);
     return;
   }
-  if (s->use_tp)
-    hipLaunchKernelGGL(s->dm.solver == 0 ? k_tp_pgs : s->dm.solver == 1 ? k_tp_cg : s->dm.integrator == 1 ? k_tp_rk4 : k_tp,
+  if (s->use_tp) {
+    const bool rk = s->dm.integrator == 1;
+    hipLaunchKernelGGL(s->dm.solver == 0 ? (rk ? k_tp_rk4_pgs : k_tp_pgs) : s->dm.solver == 1 ? (rk ? k_tp_rk4_cg : k_tp_cg) : rk ? k_tp_rk4 : k_tp,
                        grid_tp(s), dim3(64),
                        s->dm.solver == 0 ? (size_t)2 * s->dm.nbody * tp_minv_stride(s->dm.nbody) * sizeof(double) : 0, s->stream, s->dm, s->tp, s->dd,
                        n_steps, 0, 1);
-  else
+  } else {
     hipLaunchKernelGGL(k_step, grid_for(s), dim3(BS_BLOCK), 0, s->stream, s->dm, s->dd, n_steps);
+  }
 }
 
 extern "C" int bs_sim_create(const bs_model* const* models, int n_models, const int32_t* env_model_id,
@@ -1108,10 +1126,9 @@ extern "C" int bs_sim_create(const bs_model* const* models, int n_models, const 
   s->cm = img->cm;
   s->cm.maxcon = (opt && opt->max_contacts_per_env > 0) ? opt->max_contacts_per_env : 32;
   s->cm.maxcand = model->d.npair < 256 ? model->d.npair : 256;
-  // Newton with either integrator, CG with Euler; PGS (dual) with Euler and without contacts
+  // contact-free: every solver with either integrator; with contacts: Newton (Euler, RK4) and CG (Euler)
   const bool tp_solver = model->d.solver == 2 || (model->d.solver == 1 && model->d.integrator == 0);
-  const bool tp_pgs = model->d.solver == 0 && model->d.integrator == 0;
-  s->use_tp = !contacts && (tp_solver || tp_pgs) && model->tp_ok && !(kv && strcmp(kv, "serial") == 0);
+  s->use_tp = !contacts && model->tp_ok && !(kv && strcmp(kv, "serial") == 0);
   s->use_tpc = contacts && tp_solver && model->tp_ok && s->cm.maxcon <= TP_LPE &&
                !(kv && strcmp(kv, "serial") == 0);
   {

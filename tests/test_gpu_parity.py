@@ -893,3 +893,37 @@ def test_nan_guard_with_contacts(hand_model, kernel, monkeypatch):
     keep = np.ones(E, bool); keep[[3, 65]] = False
     assert np.array_equal(q0[keep], q1[keep])
     assert abs(t1[3] - 3 * m.opt_timestep) < 1e-12 and abs(t1[0] - 6 * m.opt_timestep) < 1e-12  # reset restarts the clock
+
+
+@pytest.mark.parametrize("solver", ["cg", "pgs"])
+def test_rk4_with_cg_and_pgs_tree_parallel(hand_model, solver, monkeypatch):
+    """RK4 with the non-default solvers, contact-free, in the tree-parallel kernels (k_tp_rk4_cg /
+    k_tp_rk4_pgs): against the serial kernels and the oracle."""
+    import torch
+    from mujoco_amd import BatchSim, workload
+    from mujoco_amd.model import SOL_CG, SOL_PGS
+    from oracle import OracleSim
+    m = workload.contact_free(hand_model)
+    m.opt_solver = SOL_CG if solver == "cg" else SOL_PGS
+    m.opt_integrator = 1
+    E, n = 34, 4
+    q, v = workload.config2_state(m, E, seed=1241)
+    c = workload.config2_ctrl(m, E, seed=1241)
+    res = {}
+    for kern in ("tp", "serial"):
+        if kern == "serial":
+            monkeypatch.setenv("BS_KERNEL", "serial")
+        sim = BatchSim(m, n_envs=E)
+        sim.data.qpos.copy_(torch.as_tensor(q)); sim.data.ctrl.copy_(torch.as_tensor(c))
+        sim.step(n); sim.sync()
+        res[kern] = [getattr(sim.data, f).cpu().numpy().copy() for f in ("qpos", "qvel")]
+        del sim
+    monkeypatch.delenv("BS_KERNEL")
+    for a, b in zip(res["tp"], res["serial"]):
+        assert np.abs(a - b).max() <= 1e-7 * max(1.0, np.abs(b).max())
+    for e in range(0, E, 8):
+        s = OracleSim(m)
+        s.qpos[:] = q[e]; s.ctrl[:] = c[e]
+        s.step(n)
+        assert np.abs(res["tp"][0][e] - s.qpos).max() < 1e-8
+        assert np.abs(res["tp"][1][e] - s.qvel).max() < 1e-7 * max(1.0, np.abs(s.qvel).max())
