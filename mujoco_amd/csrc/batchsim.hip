@@ -1126,8 +1126,8 @@ extern "C" int bs_sim_create(const bs_model* const* models, int n_models, const 
   s->cm = img->cm;
   s->cm.maxcon = (opt && opt->max_contacts_per_env > 0) ? opt->max_contacts_per_env : 32;
   s->cm.maxcand = model->d.npair < 256 ? model->d.npair : 256;
-  // contact-free: every solver with either integrator; with contacts: Newton (Euler, RK4) and CG (Euler)
-  const bool tp_solver = model->d.solver == 2 || (model->d.solver == 1 && model->d.integrator == 0);
+  // contact-free: every solver with either integrator; with contacts: Newton and CG with either integrator
+  const bool tp_solver = model->d.solver == 2 || model->d.solver == 1;
   s->use_tp = !contacts && model->tp_ok && !(kv && strcmp(kv, "serial") == 0);
   s->use_tpc = contacts && tp_solver && model->tp_ok && s->cm.maxcon <= TP_LPE &&
                !(kv && strcmp(kv, "serial") == 0);
