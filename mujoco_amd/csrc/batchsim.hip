@@ -11,9 +11,7 @@
 #include <string>
 #include <vector>
 
-#include "physics_dev.h"
-#include "physics_tp.h"
-#include "physics_contact.h"
+#include "kernels.h"
 #include <cstdlib>
 
 // ------------------------------------------------------------------ errors
@@ -657,325 +655,6 @@ struct bs_sim {
   if (!(s)->parts.empty())                                                                            \
     return fail(BS_ERR_UNSUPPORTED, what ": a mixed-model sim has one field set per model; use bs_sim_part")
 
-// kernels ----------------------------------------------------------------------------------
-#define BS_BLOCK 64
-
-__global__ __launch_bounds__(BS_BLOCK) void k_step(DevModel m, DevData d, int nsteps) {
-  const long e = (long)blockIdx.x * BS_BLOCK + threadIdx.x;
-  if (e >= d.n_envs) return;
-  for (int s = 0; s < nsteps; s++) env_step(m, d, e);
-}
-// tree-parallel kernel: 2 environments per 64-lane block (physics_tp.h)
-__global__ __launch_bounds__(64, 2) void k_tp(DevModel m, TpModel t, DevData d, int nsteps, int mode, int dump) {
-  __shared__ int tbl[TPL_TOTAL * 64];
-  __shared__ double park[(TP_MAXD + 1) * 64];
-  const TpShared sh = {tbl, nullptr, nullptr, nullptr, park};
-  ColModel cm;
-  ColData cd;
-  tp_run<false, false, false>(m, t, d, nsteps, mode, dump, sh, cm, cd);
-}
-// same with solver = CG (Euler only; bs_forward and RK4 with CG run on the serial kernels)
-__global__ __launch_bounds__(64, 2) void k_tp_cg(DevModel m, TpModel t, DevData d, int nsteps, int mode, int dump) {
-  __shared__ int tbl[TPL_TOTAL * 64];
-  __shared__ double park[(TP_MAXD + 1) * 64];
-  const TpShared sh = {tbl, nullptr, nullptr, nullptr, park};
-  ColModel cm;
-  ColData cd;
-  tp_run<false, false, false, true>(m, t, d, nsteps, mode, dump, sh, cm, cd);
-}
-// same with solver = PGS (contact-free, Euler): M^-1 of the two environments lives in LDS
-__global__ __launch_bounds__(64, 2) void k_tp_pgs(DevModel m, TpModel t, DevData d, int nsteps, int mode, int dump) {
-  __shared__ int tbl[TPL_TOTAL * 64];
-  extern __shared__ double minv[];  // 2 x nbody x tp_minv_stride(nbody)
-  const TpShared sh = {tbl, nullptr, nullptr, nullptr, nullptr, minv};
-  ColModel cm;
-  ColData cd;
-  tp_run<false, false, false, false, true>(m, t, d, nsteps, mode, dump, sh, cm, cd);
-}
-// RK4 with CG / PGS
-__global__ __launch_bounds__(64, 2) void k_tp_rk4_cg(DevModel m, TpModel t, DevData d, int nsteps, int mode, int dump) {
-  __shared__ int tbl[TPL_TOTAL * 64];
-  const TpShared sh = {tbl, nullptr, nullptr, nullptr, nullptr};
-  ColModel cm;
-  ColData cd;
-  tp_run<false, false, true, true>(m, t, d, nsteps, mode, dump, sh, cm, cd);
-}
-__global__ __launch_bounds__(64, 2) void k_tp_rk4_pgs(DevModel m, TpModel t, DevData d, int nsteps, int mode, int dump) {
-  __shared__ int tbl[TPL_TOTAL * 64];
-  extern __shared__ double minv[];
-  const TpShared sh = {tbl, nullptr, nullptr, nullptr, nullptr, minv};
-  ColModel cm;
-  ColData cd;
-  tp_run<false, false, true, false, true>(m, t, d, nsteps, mode, dump, sh, cm, cd);
-}
-// same with the RK4 integrator (three extra forward passes per step)
-__global__ __launch_bounds__(64, 2) void k_tp_rk4(DevModel m, TpModel t, DevData d, int nsteps, int mode, int dump) {
-  __shared__ int tbl[TPL_TOTAL * 64];
-  const TpShared sh = {tbl, nullptr, nullptr, nullptr, nullptr};
-  ColModel cm;
-  ColData cd;
-  tp_run<false, false, true>(m, t, d, nsteps, mode, dump, sh, cm, cd);
-}
-// same, with every intermediate the parity tests read written out (bs_forward)
-__global__ __launch_bounds__(64, 2) void k_tp_full(DevModel m, TpModel t, DevData d, int nsteps, int mode, int dump) {
-  __shared__ int tbl[TPL_TOTAL * 64];
-  const TpShared sh = {tbl, nullptr, nullptr, nullptr, nullptr};
-  ColModel cm;
-  ColData cd;
-  tp_run<false, true, false>(m, t, d, nsteps, mode, dump, sh, cm, cd);
-}
-// kinematics + geom frames + broadphase, tree-parallel layout (physics_tp.h::tp_collide_prep)
-__global__ __launch_bounds__(64) void k_tp_col(DevModel m, TpModel t, DevData d, ColModel cm, ColData cd) {
-  extern __shared__ double tpg_dyn[];  // geom frames of the two environments
-  tp_collide_prep(m, t, d, cm, cd, tpg_dyn);
-}
-// tree-parallel step with contacts: candidates from k_tp_col + the narrowphase kernel, one step per launch
-#ifndef TPC_OCC
-#define TPC_OCC 2
-#endif
-__global__ __launch_bounds__(64, TPC_OCC) void k_tpc(DevModel m, TpModel t, DevData d, ColModel cm, ColData cd, int mode,
-                                               int dump) {
-  // dynamic LDS: packed Hessians for nbody rows (2 envs), then contact slots, then the U staging rows
-  __shared__ int tbl[TPL_TOTAL * 64];
-  extern __shared__ double tpc_dyn[];
-  const int ntri = m.nbody * (m.nbody + 1) / 2;
-  const TpShared sh = {tbl, tpc_dyn, tpc_dyn + 2 * ntri, tpc_dyn + 2 * ntri + 2 * TP_LPE * TPC_SLOT};
-  tp_run<true, false, false>(m, t, d, 1, mode, dump, sh, cm, cd);
-}
-__global__ __launch_bounds__(64, TPC_OCC) void k_tpc_cg(DevModel m, TpModel t, DevData d, ColModel cm, ColData cd, int mode,
-                                                  int dump) {
-  __shared__ int tbl[TPL_TOTAL * 64];
-  extern __shared__ double tpc_dyn[];
-  const int ntri = m.nbody * (m.nbody + 1) / 2;
-  const TpShared sh = {tbl, tpc_dyn, tpc_dyn + 2 * ntri, tpc_dyn + 2 * ntri + 2 * TP_LPE * TPC_SLOT};
-  tp_run<true, false, false, true>(m, t, d, 1, mode, dump, sh, cm, cd);
-}
-__global__ __launch_bounds__(BS_BLOCK) void k_forward(DevModel m, DevData d) {
-  const long e = (long)blockIdx.x * BS_BLOCK + threadIdx.x;
-  if (e >= d.n_envs) return;
-  env_forward(m, d, e);
-}
-// single stage, for per-stage timing: 0 check+position+factor, 2 velocity, 3 constraint, 4 integrate
-__global__ __launch_bounds__(BS_BLOCK) void k_stage(DevModel m, DevData d, int stage) {
-  const long e = (long)blockIdx.x * BS_BLOCK + threadIdx.x;
-  if (e >= d.n_envs) return;
-  switch (stage) {
-    case 0:
-      env_check(m, d, e, d.qpos, m.njnt, 0);
-      env_check(m, d, e, d.qvel, m.nv, 1);
-      stage_position(m, d, e);
-      stage_factor(m, d, e);
-      break;
-    case 2: stage_velocity(m, d, e); break;
-    case 3:
-      if (m.solver == 0) stage_constraint_pgs(m, d, e);
-      else stage_constraint(m, d, e);
-      break;
-    case 4:
-      if (env_check(m, d, e, d.qacc, m.nv, 2)) env_forward(m, d, e);
-      if (m.integrator == 1) stage_rk4(m, d, e);
-      else stage_euler(m, d, e);
-      break;
-    default: break;
-  }
-}
-__global__ __launch_bounds__(BS_BLOCK) void k_reset(DevModel m, DevData d, const uint8_t* mask) {
-  const long e = (long)blockIdx.x * BS_BLOCK + threadIdx.x;
-  if (e >= d.n_envs) return;
-  if (mask && !mask[e]) return;
-  env_reset(m, d, e);
-  const long E = d.E;
-  AT(d.warning, 0) = 0;
-}
-// A14 mj_checkPos / mj_checkVel on their own (the RK4 step with contacts starts with it)
-__global__ __launch_bounds__(BS_BLOCK) void k_check_state(DevModel m, DevData d) {
-  const long e = (long)blockIdx.x * BS_BLOCK + threadIdx.x;
-  if (e >= d.n_envs) return;
-  env_check(m, d, e, d.qpos, m.njnt, 0);
-  env_check(m, d, e, d.qvel, m.nv, 1);
-}
-// RK4 across launches (contacts): see rk4_advance
-__global__ __launch_bounds__(BS_BLOCK) void k_rk4_advance(DevModel m, DevData d, int i) {
-  const long e = (long)blockIdx.x * BS_BLOCK + threadIdx.x;
-  if (e >= d.n_envs) return;
-  rk4_advance(m, d, e, i);
-}
-// on-demand frames: xmat[9*nbody], geom_xpos[3*ngeom], geom_xmat[9*ngeom] from xpos/xquat
-__global__ __launch_bounds__(BS_BLOCK) void k_frames(DevModel m, DevData d, double* xmat, double* gpos,
-                                                     double* gmat) {
-  const long e = (long)blockIdx.x * BS_BLOCK + threadIdx.x;
-  if (e >= d.n_envs) return;
-  const long E = d.E;
-  for (int b = 0; b < m.nbody; b++) {
-    Q4 q = {AT(d.xquat, 4 * b), AT(d.xquat, 4 * b + 1), AT(d.xquat, 4 * b + 2), AT(d.xquat, 4 * b + 3)};
-    M3 R = q2m(q);
-    for (int k = 0; k < 9; k++) AT(xmat, 9 * b + k) = R.a[k];
-  }
-  for (int g = 0; g < m.ngeom; g++) {
-    const int b = m.geom_bodyid[g];
-    Q4 q = {AT(d.xquat, 4 * b), AT(d.xquat, 4 * b + 1), AT(d.xquat, 4 * b + 2), AT(d.xquat, 4 * b + 3)};
-    M3 R = q2m(q);
-    V3 p = mrot(R, ld3(m.geom_pos + 3 * g));
-    AT(gpos, 3 * g) = AT(d.xpos, 3 * b) + p.x;
-    AT(gpos, 3 * g + 1) = AT(d.xpos, 3 * b + 1) + p.y;
-    AT(gpos, 3 * g + 2) = AT(d.xpos, 3 * b + 2) + p.z;
-    M3 G = q2m(qmul(q, ld4(m.geom_quat + 4 * g)));
-    for (int k = 0; k < 9; k++) AT(gmat, 9 * g + k) = G.a[k];
-  }
-}
-
-// ---- contact pipeline (serial layout): position -> broadphase -> narrowphase -> dynamics
-__global__ __launch_bounds__(BS_BLOCK) void k_c_pos(DevModel m, DevData d, ColData c, int check) {
-  const long e = (long)blockIdx.x * BS_BLOCK + threadIdx.x;
-  if (e >= d.n_envs) return;
-  if (check) {
-    env_check(m, d, e, d.qpos, m.njnt, 0);
-    env_check(m, d, e, d.qvel, m.nv, 1);
-  }
-  stage_position(m, d, e);
-  stage_factor(m, d, e);
-  col_geom_frames(m, d, c, e);
-}
-__global__ __launch_bounds__(64) void k_c_broad(ColModel cm, DevData d, ColData c) {
-  const long e = blockIdx.x;  // one wavefront per environment
-  if (e >= d.n_envs) return;
-  col_broadphase(cm, d, c, e, threadIdx.x);
-}
-// narrowphase over the flattened (environment, candidate slot) items of NB_ENVS environments:
-// an exclusive scan of the candidate counts in LDS, then every lane takes items round-robin, so
-// no lane idles on environments with few candidates and no wavefront is launched for empty slots
-#ifndef NB_ENVS
-#define NB_ENVS 16
-#endif
-#ifndef NB_THREADS
-#define NB_THREADS 128
-#endif
-__global__ __launch_bounds__(NB_THREADS) void k_c_narrow_flat(ColModel cm, DevData d, ColData c) {
-  __shared__ int pre[NB_ENVS + 1];
-  __shared__ MprState mpr[NB_THREADS];  // MPR state of every lane (see mpr_penetration)
-  const long e0 = d.env0 + (long)blockIdx.x * NB_ENVS;
-  const int tid = threadIdx.x;
-  if (tid < NB_ENVS) {  // first wavefront: inclusive scan of the candidate counts with DPP-free shuffles
-    const long e = e0 + tid, E = d.E;
-    int v = e < d.n_envs ? AT(c.ncand, 0) : 0;
-    for (int off = 1; off < NB_ENVS; off <<= 1) {
-      const int u = __shfl_up(v, off, 64);
-      if (tid >= off) v += u;
-    }
-    pre[tid + 1] = v;
-    if (tid == 0) pre[0] = 0;
-  }
-  __syncthreads();
-  const int total = pre[NB_ENVS];
-  unsigned acc[2] = {0, 0};
-  for (int item = tid; item < total; item += NB_THREADS) {
-    int lo = 0, hi = NB_ENVS;  // largest env index with pre[env] <= item
-    while (hi - lo > 1) {
-      const int mid = (lo + hi) >> 1;
-      if (pre[mid] <= item) lo = mid;
-      else hi = mid;
-    }
-    col_narrowphase(cm, d, c, e0 + lo, item - pre[lo], acc, mpr[tid]);
-  }
-  if (c.stat) {  // work counters: wavefront reduction, then one atomic each
-    for (int off = 32; off > 0; off >>= 1) {
-      acc[0] += __shfl_down(acc[0], off, 64);
-      acc[1] += __shfl_down(acc[1], off, 64);
-    }
-    if ((tid & 63) == 0 && acc[0]) {
-      atomicAdd(c.stat, (unsigned long long)acc[0]);
-      atomicAdd(c.stat + 1, (unsigned long long)acc[1]);
-    }
-  }
-}
-#define NW_THREADS 128
-__global__ __launch_bounds__(NW_THREADS) void k_c_narrow_ws(ColModel cm, DevData d, ColData c) {
-  __shared__ int pre[NB_ENVS + 1];
-  __shared__ int next;
-  const long e0 = d.env0 + (long)blockIdx.x * NB_ENVS;
-  const int tid = threadIdx.x;
-  if (tid < NB_ENVS) {
-    const long e = e0 + tid, E = d.E;
-    int v = e < d.n_envs ? AT(c.ncand, 0) : 0;
-    for (int off = 1; off < NB_ENVS; off <<= 1) {
-      const int u = __shfl_up(v, off, 64);
-      if (tid >= off) v += u;
-    }
-    pre[tid + 1] = v;
-    if (tid == 0) { pre[0] = 0; next = 0; }
-  }
-  __syncthreads();
-  unsigned acc[2] = {0, 0};
-  col_narrow_ws(cm, d, c, e0, pre, NB_ENVS, &next, acc);
-  if (c.stat) {
-    for (int off = 32; off > 0; off >>= 1) {
-      acc[0] += __shfl_down(acc[0], off, 64);
-      acc[1] += __shfl_down(acc[1], off, 64);
-    }
-    if ((tid & 63) == 0 && acc[0]) {
-      atomicAdd(c.stat, (unsigned long long)acc[0]);
-      atomicAdd(c.stat + 1, (unsigned long long)acc[1]);
-    }
-  }
-}
-__global__ __launch_bounds__(BS_BLOCK) void k_c_dyn(DevModel m, ColModel cm, DevData d, ColData c, ConData k,
-                                                    int integrate, int lds_hessian) {
-  extern __shared__ double hs_lds[];  // dense Hessian + one Jacobian row per lane, [entry][64]
-  const long e = (long)blockIdx.x * BS_BLOCK + threadIdx.x;
-  if (e >= d.n_envs) return;
-  col_assemble(cm, d, c, e);
-  stage_velocity(m, d, e);
-  stage_constraint_c(m, cm, d, c, k, e, lds_hessian ? hs_lds : nullptr);
-  if (integrate) {
-    // mj_checkAcc: a bad acceleration resets the environment; the next step recomputes everything
-    if (!env_check(m, d, e, d.qacc, m.nv, 2)) stage_euler(m, d, e);
-  }
-}
-
-#ifndef NL_THREADS
-#define NL_THREADS 64  // one wavefront per block measured best (3.21 / 3.25 / 3.30 ms per step for 64 / 128 / 256)
-#endif
-// narrowphase over the work list k_tp_col wrote: one lane per item whatever environment it belongs
-// to, so every wavefront but the last is full
-__global__ __launch_bounds__(NL_THREADS) void k_c_narrow_list(ColModel cm, DevData d, ColData c) {
-  __shared__ unsigned pre[BS_NSUB + 1];
-  __shared__ MprState mpr[NL_THREADS];
-  const int tid = threadIdx.x;
-  if (tid < BS_NSUB) {  // first wavefront: inclusive scan of the sub-list lengths
-    unsigned v = (unsigned)c.stat[BS_STAT_ITEMS + d.range * BS_NSUB + tid];
-    for (int off = 1; off < BS_NSUB; off <<= 1) {
-      const unsigned u = __shfl_up(v, off, 64);
-      if (tid >= off) v += u;
-    }
-    pre[tid + 1] = v;
-    if (tid == 0) pre[0] = 0;
-  }
-  __syncthreads();
-  const unsigned total = pre[BS_NSUB];
-  const int* items = c.items + col_items_base(d.env0, d.range, cm.maxcand);
-  const long subcap = col_items_subcap(d.n_envs - d.env0, cm.maxcand);
-  unsigned acc[2] = {0, 0};
-  for (unsigned i = blockIdx.x * NL_THREADS + tid; i < total; i += gridDim.x * NL_THREADS) {
-    int lo = 0, hi = BS_NSUB;  // sub-list of item i: largest s with pre[s] <= i
-    while (hi - lo > 1) {
-      const int mid = (lo + hi) >> 1;
-      if (pre[mid] <= i) lo = mid;
-      else hi = mid;
-    }
-    const int it = items[lo * subcap + (i - pre[lo])];
-    col_narrowphase(cm, d, c, d.env0 + (it >> 8), it & 255, acc, mpr[tid]);
-  }
-  if (c.stat) {
-    for (int off = 32; off > 0; off >>= 1) {
-      acc[0] += __shfl_down(acc[0], off, 64);
-      acc[1] += __shfl_down(acc[1], off, 64);
-    }
-    if ((tid & 63) == 0 && acc[0]) {
-      atomicAdd(c.stat, (unsigned long long)acc[0]);
-      atomicAdd(c.stat + 1, (unsigned long long)acc[1]);
-    }
-  }
-}
 
 static inline dim3 grid_for(const bs_sim* s) { return dim3((unsigned)((s->n_envs + BS_BLOCK - 1) / BS_BLOCK)); }
 static inline dim3 grid_tp(const bs_sim* s) { return dim3((unsigned)((s->n_envs + 1) / 2)); }
@@ -984,26 +663,26 @@ static inline dim3 grid_tp(const bs_sim* s) { return dim3((unsigned)((s->n_envs 
 static void launch_narrow(bs_sim* s, const DevData& dd, hipStream_t st) {
   const dim3 g((unsigned)((dd.n_envs - dd.env0 + NB_ENVS - 1) / NB_ENVS));
   if (s->narrow_ws)
-    hipLaunchKernelGGL(k_c_narrow_ws, g, dim3(NW_THREADS), 0, st, s->cm, dd, s->cd);
+    bs_launch_narrow_ws(g, st, s->cm, dd, s->cd);
   else
-    hipLaunchKernelGGL(k_c_narrow_flat, g, dim3(NB_THREADS), 0, st, s->cm, dd, s->cd);
+    bs_launch_narrow_flat(g, st, s->cm, dd, s->cd);
 }
 // one forward pass (mode 1) or step (mode 0) with contacts through the tree-parallel kernels, for
 // the environments [dd.env0, dd.n_envs) on stream st
 static void launch_tpc_pass(bs_sim* s, const DevData& dd, hipStream_t st, int mode, int dump) {
   const dim3 g((unsigned)((dd.n_envs - dd.env0 + 1) / 2));
   const size_t lds_col = (size_t)2 * s->cm.ngeom * TPG_SLOT * sizeof(double);
-  hipLaunchKernelGGL(k_tp_col, g, dim3(64), lds_col, st, s->dm, s->tp, dd, s->cm, s->cd);
+  bs_launch_tp_col(g, lds_col, st, s->dm, s->tp, dd, s->cm, s->cd);
   if (s->narrow_ws || s->narrow_blocks) {
     launch_narrow(s, dd, st);
   } else {
     size_t nb = ((size_t)(dd.n_envs - dd.env0) * s->cm.maxcand + NL_THREADS - 1) / NL_THREADS;
     nb = nb < 1 ? 1 : nb > 16384 ? 16384 : nb;
-    hipLaunchKernelGGL(k_c_narrow_list, dim3((unsigned)nb), dim3(NL_THREADS), 0, st, s->cm, dd, s->cd);
+    bs_launch_narrow_list(dim3((unsigned)nb), st, s->cm, dd, s->cd);
   }
   const int ntri = s->dm.nbody * (s->dm.nbody + 1) / 2;
   const size_t lds = (size_t)(2 * ntri + 2 * TP_LPE * TPC_SLOT + 2 * TP_LPE * 3) * sizeof(double);
-  hipLaunchKernelGGL(s->dm.solver == 1 ? k_tpc_cg : k_tpc, g, dim3(64), lds, st, s->dm, s->tp, dd, s->cm, s->cd, mode, dump);
+  (s->dm.solver == 1 ? bs_launch_tpc_cg : bs_launch_tpc)(g, lds, st, s->dm, s->tp, dd, s->cm, s->cd, mode, dump);
 }
 // check: mj_checkPos/Vel first; integrate: mj_step (Euler) rather than mj_forward; fast: let the
 // tree-parallel kernels run a forward pass too (they leave the position-stage intermediates of
@@ -1014,10 +693,10 @@ static void launch_contact_pass(bs_sim* s, int check, int integrate, int dump = 
     return;
   }
   const dim3 g = dim3((unsigned)((s->n_envs + BS_BLOCK - 1) / BS_BLOCK));
-  hipLaunchKernelGGL(k_c_pos, g, dim3(BS_BLOCK), 0, s->stream, s->dm, s->dd, s->cd, check);
-  hipLaunchKernelGGL(k_c_broad, dim3((unsigned)s->n_envs), dim3(64), 0, s->stream, s->cm, s->dd, s->cd);
+  bs_launch_c_pos(g, s->stream, s->dm, s->dd, s->cd, check);
+  bs_launch_c_broad(dim3((unsigned)s->n_envs), s->stream, s->cm, s->dd, s->cd);
   launch_narrow(s, s->dd, s->stream);
-  hipLaunchKernelGGL(k_c_dyn, g, dim3(BS_BLOCK), s->hs_bytes, s->stream, s->dm, s->cm, s->dd, s->cd, s->kd, integrate,
+  bs_launch_c_dyn(g, s->hs_bytes, s->stream, s->dm, s->cm, s->dd, s->cd, s->kd, integrate,
                      s->hs_bytes ? 1 : 0);
 }
 static void launch_step(bs_sim* s, int n_steps) {
@@ -1026,9 +705,9 @@ static void launch_step(bs_sim* s, int n_steps) {
     if (s->dm.integrator == 1) {  // RK4: four forward passes (collision included), state moved in between
       for (int k = 0; k < n_steps; k++)
         for (int i = 1; i <= 4; i++) {
-          if (i == 1) hipLaunchKernelGGL(k_check_state, grid_for(s), dim3(BS_BLOCK), 0, s->stream, s->dm, s->dd);
+          if (i == 1) bs_launch_check_state(grid_for(s), s->stream, s->dm, s->dd);
           launch_contact_pass(s, 0, 0, i == 4 && k == n_steps - 1, 1);
-          hipLaunchKernelGGL(k_rk4_advance, grid_for(s), dim3(BS_BLOCK), 0, s->stream, s->dm, s->dd, i);
+          bs_launch_rk4_advance(grid_for(s), s->stream, s->dm, s->dd, i);
         }
       return;
     }
@@ -1059,12 +738,12 @@ static void launch_step(bs_sim* s, int n_steps) {
   }
   if (s->use_tp) {
     const bool rk = s->dm.integrator == 1;
-    hipLaunchKernelGGL(s->dm.solver == 0 ? (rk ? k_tp_rk4_pgs : k_tp_pgs) : s->dm.solver == 1 ? (rk ? k_tp_rk4_cg : k_tp_cg) : rk ? k_tp_rk4 : k_tp,
-                       grid_tp(s), dim3(64),
-                       s->dm.solver == 0 ? (size_t)2 * s->dm.nbody * tp_minv_stride(s->dm.nbody) * sizeof(double) : 0, s->stream, s->dm, s->tp, s->dd,
-                       n_steps, 0, 1);
+    auto* launch = s->dm.solver == 0 ? (rk ? bs_launch_tp_rk4_pgs : bs_launch_tp_pgs)
+                   : s->dm.solver == 1 ? (rk ? bs_launch_tp_rk4_cg : bs_launch_tp_cg) : (rk ? bs_launch_tp_rk4 : bs_launch_tp);
+    launch(grid_tp(s), s->dm.solver == 0 ? (size_t)2 * s->dm.nbody * tp_minv_stride(s->dm.nbody) * sizeof(double) : 0, s->stream,
+           s->dm, s->tp, s->dd, n_steps, 0, 1);
   } else {
-    hipLaunchKernelGGL(k_step, grid_for(s), dim3(BS_BLOCK), 0, s->stream, s->dm, s->dd, n_steps);
+    bs_launch_step(grid_for(s), s->stream, s->dm, s->dd, n_steps);
   }
 }
 
@@ -1240,7 +919,7 @@ extern "C" int bs_sim_create(const bs_model* const* models, int n_models, const 
     // dense Hessian in LDS when (nv(nv+1)/2 + nv) x 64 lanes x 8 B fits one CU's 160 KB
     const size_t want = (nh + (size_t)nv) * BS_BLOCK * sizeof(double);
     if (want <= 160 * 1024 && getenv("BS_LDS_HESSIAN")) {  // opt-in: lowers occupancy to one wave per CU
-      if (hipFuncSetAttribute((const void*)k_c_dyn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want) == hipSuccess)
+      if (bs_c_dyn_set_lds((int)want) == hipSuccess)
         s->hs_bytes = want;
       else
         (void)hipGetLastError();
@@ -1263,7 +942,7 @@ extern "C" int bs_sim_create(const bs_model* const* models, int n_models, const 
       }
     }
   }
-  hipLaunchKernelGGL(k_reset, grid_for(s), dim3(BS_BLOCK), 0, s->stream, s->dm, s->dd, (const uint8_t*)nullptr);
+  bs_launch_reset(grid_for(s), s->stream, s->dm, s->dd, (const uint8_t*)nullptr);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(s->stream));
   *out = s;
@@ -1343,9 +1022,9 @@ extern "C" int bs_forward(bs_sim* s) {
   if (s->contacts)
     launch_contact_pass(s, 0, 0);
   else if (s->use_tp && s->dm.solver == 2)
-    hipLaunchKernelGGL(k_tp_full, grid_tp(s), dim3(64), 0, s->stream, s->dm, s->tp, s->dd, 1, 1, 2);
+    bs_launch_tp_full(grid_tp(s), 0, s->stream, s->dm, s->tp, s->dd, 1, 1, 2);
   else
-    hipLaunchKernelGGL(k_forward, grid_for(s), dim3(BS_BLOCK), 0, s->stream, s->dm, s->dd);
+    bs_launch_forward(grid_for(s), s->stream, s->dm, s->dd);
   HIPCHK(hipGetLastError());
   return BS_OK;
 }
@@ -1365,7 +1044,7 @@ extern "C" int bs_reset(bs_sim* s, const uint8_t* env_mask) {
     HIPCHK(hipMalloc((void**)&dmask, (size_t)s->n_envs));
     HIPCHK(hipMemcpyAsync(dmask, env_mask, (size_t)s->n_envs, hipMemcpyHostToDevice, s->stream));
   }
-  hipLaunchKernelGGL(k_reset, grid_for(s), dim3(BS_BLOCK), 0, s->stream, s->dm, s->dd, (const uint8_t*)dmask);
+  bs_launch_reset(grid_for(s), s->stream, s->dm, s->dd, (const uint8_t*)dmask);
   HIPCHK(hipGetLastError());
   if (dmask) {
     HIPCHK(hipStreamSynchronize(s->stream));
@@ -1375,7 +1054,7 @@ extern "C" int bs_reset(bs_sim* s, const uint8_t* env_mask) {
 }
 
 static int refresh_derived(bs_sim* s) {
-  hipLaunchKernelGGL(k_frames, grid_for(s), dim3(BS_BLOCK), 0, s->stream, s->dm, s->dd,
+  bs_launch_frames(grid_for(s), s->stream, s->dm, s->dd,
                      (double*)s->fields[BS_F_XMAT].ptr, (double*)s->fields[BS_F_GEOM_XPOS].ptr,
                      (double*)s->fields[BS_F_GEOM_XMAT].ptr);
   HIPCHK(hipGetLastError());
@@ -1469,16 +1148,7 @@ extern "C" int bs_collision_stats(bs_sim* s, uint64_t out[3], int reset) {
   HIPCHK(hipStreamSynchronize(s->stream));
   HIPCHK(hipMemcpy(out, s->cd.stat, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost));
 #ifdef NP_PROFILE
-  {
-    unsigned long long hc[32], hs[64];
-    HIPCHK(hipMemcpyFromSymbol(hc, HIP_SYMBOL(np_hist_climb), sizeof hc));
-    HIPCHK(hipMemcpyFromSymbol(hs, HIP_SYMBOL(np_hist_sup), sizeof hs));
-    fprintf(stderr, "climb trips per support:");
-    for (int q = 0; q < 32; q++) fprintf(stderr, " %llu", hc[q]);
-    fprintf(stderr, "\nsupport pairs per item:");
-    for (int q = 0; q < 64; q++) fprintf(stderr, " %llu", hs[q]);
-    fprintf(stderr, "\n");
-  }
+  bs_np_profile_dump();
 #endif
 #ifdef TPC_PROFILE
   {
@@ -1508,12 +1178,12 @@ extern "C" int bs_stage_times(bs_sim* s, double* ms, int n) {
   if (s->contacts) {
     const dim3 g = dim3((unsigned)((s->n_envs + BS_BLOCK - 1) / BS_BLOCK));
     HIPCHK(hipEventRecord(s->ev[0], s->stream));
-    hipLaunchKernelGGL(k_c_pos, g, dim3(BS_BLOCK), 0, s->stream, s->dm, s->dd, s->cd, 1);
+    bs_launch_c_pos(g, s->stream, s->dm, s->dd, s->cd, 1);
     HIPCHK(hipEventRecord(s->ev[1], s->stream));
-    hipLaunchKernelGGL(k_c_broad, dim3((unsigned)s->n_envs), dim3(64), 0, s->stream, s->cm, s->dd, s->cd);
+    bs_launch_c_broad(dim3((unsigned)s->n_envs), s->stream, s->cm, s->dd, s->cd);
     launch_narrow(s, s->dd, s->stream);
     HIPCHK(hipEventRecord(s->ev[2], s->stream));
-    hipLaunchKernelGGL(k_c_dyn, g, dim3(BS_BLOCK), s->hs_bytes, s->stream, s->dm, s->cm, s->dd, s->cd, s->kd, 1,
+    bs_launch_c_dyn(g, s->hs_bytes, s->stream, s->dm, s->cm, s->dd, s->cd, s->kd, 1,
                        s->hs_bytes ? 1 : 0);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(s->ev[3], s->stream));
@@ -1526,7 +1196,7 @@ extern "C" int bs_stage_times(bs_sim* s, double* ms, int n) {
   const int stages[4] = {0, 2, 3, 4};
   HIPCHK(hipEventRecord(s->ev[0], s->stream));
   for (int k = 0; k < 4; k++) {
-    hipLaunchKernelGGL(k_stage, grid_for(s), dim3(BS_BLOCK), 0, s->stream, s->dm, s->dd, stages[k]);
+    bs_launch_stage(grid_for(s), s->stream, s->dm, s->dd, stages[k]);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(s->ev[k + 1], s->stream));
   }
@@ -1537,21 +1207,6 @@ extern "C" int bs_stage_times(bs_sim* s, double* ms, int n) {
   return BS_OK;
 }
 
-// obs = qpos | qvel as fp32, reward = -|qpos[actuated joints] - ctrl|^2; lane = environment
-// (coalesced reads of the [row][E] fields; rows of the output are written by their own lane)
-__global__ __launch_bounds__(256) void k_pack_obs(DevModel m, DevData d, float* out, long stride, int nq) {
-  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x, E = d.E;
-  if (e >= d.n_envs) return;
-  float* o = out + e * stride;
-  for (int i = 0; i < nq; i++) o[i] = (float)AT(d.qpos, i);
-  for (int i = 0; i < m.nv; i++) o[nq + i] = (float)AT(d.qvel, i);
-  double r = 0;
-  for (int u = 0; u < m.nu; u++) {
-    const double err = AT(d.qpos, m.jnt_qposadr[m.actuator_trnid[u]]) - AT(d.ctrl, u);
-    r += err * err;
-  }
-  o[nq + m.nv] = (float)(-r);
-}
 
 extern "C" int bs_pack_obs(bs_sim* s, float* out_dev, int64_t row_stride) {
   if (!s || !out_dev) return fail(BS_ERR_INVALID, "bs_pack_obs: null argument");
@@ -1561,7 +1216,7 @@ extern "C" int bs_pack_obs(bs_sim* s, float* out_dev, int64_t row_stride) {
     return fail(BS_ERR_INVALID, "bs_pack_obs: row_stride %lld < nq + nv + 1 = %d", (long long)row_stride,
                 nq + s->dm.nv + 1);
   HIPCHK(hipSetDevice(s->device));
-  hipLaunchKernelGGL(k_pack_obs, dim3((unsigned)((s->n_envs + 255) / 256)), dim3(256), 0, s->stream, s->dm, s->dd, out_dev,
+  bs_launch_pack_obs(dim3((unsigned)((s->n_envs + 255) / 256)), s->stream, s->dm, s->dd, out_dev,
                      (long)row_stride, nq);
   HIPCHK(hipGetLastError());
   return BS_OK;

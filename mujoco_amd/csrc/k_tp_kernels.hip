@@ -1,0 +1,62 @@
+// k_tp_kernels.hip — the tree-parallel kernels (physics_tp.h), ONE instantiation of tp_run per
+// object file: the Makefile compiles this source once per kernel with -DTPK_<name>, so the
+// instantiations (each a few thousand lines of straight-line fp64 code) build in parallel.
+// Block = one 64-lane wavefront = two environments; __launch_bounds__(64, 2) = two waves per SIMD.
+#include "kernels.h"
+
+#define TP_KERNEL(name, CONTACTS_, FULL_, RK4_, CG_, PGS_, PARK_, MINV_)                                              \
+  __global__ __launch_bounds__(64, 2) void k_##name(DevModel m, TpModel t, DevData d, int nsteps, int mode, int dump) { \
+    __shared__ int tbl[TPL_TOTAL * 64];                                                                               \
+    __shared__ double park[PARK_ ? (TP_MAXD + 1) * 64 : 1];                                                           \
+    extern __shared__ double minv[]; /* PGS: 2 x nbody x tp_minv_stride(nbody) */                                     \
+    const TpShared sh = {tbl, nullptr, nullptr, nullptr, PARK_ ? park : nullptr, MINV_ ? minv : nullptr};             \
+    ColModel cm;                                                                                                      \
+    ColData cd;                                                                                                       \
+    tp_run<CONTACTS_, FULL_, RK4_, CG_, PGS_>(m, t, d, nsteps, mode, dump, sh, cm, cd);                               \
+  }                                                                                                                   \
+  void bs_launch_##name(BS_TP_ARGS) { hipLaunchKernelGGL(k_##name, g, dim3(64), lds, st, m, t, d, nsteps, mode, dump); }
+
+// contacts: candidates from k_tp_col + the narrowphase kernel, one step per launch.  Dynamic LDS:
+// packed Hessians for nbody rows (2 envs), then contact slots, then the U staging rows
+#define TPC_KERNEL(name, CG_, PGS_)                                                                                   \
+  __global__ __launch_bounds__(64, TPC_OCC) void k_##name(DevModel m, TpModel t, DevData d, ColModel cm, ColData cd,  \
+                                                          int mode, int dump) {                                      \
+    __shared__ int tbl[TPL_TOTAL * 64];                                                                               \
+    extern __shared__ double tpc_dyn[];                                                                               \
+    const int ntri = m.nbody * (m.nbody + 1) / 2;                                                                     \
+    const TpShared sh = {tbl, tpc_dyn, tpc_dyn + 2 * ntri, tpc_dyn + 2 * ntri + 2 * TP_LPE * TPC_SLOT, nullptr, nullptr}; \
+    tp_run<true, false, false, CG_, PGS_>(m, t, d, 1, mode, dump, sh, cm, cd);                                        \
+  }                                                                                                                   \
+  void bs_launch_##name(BS_TPC_ARGS) { hipLaunchKernelGGL(k_##name, g, dim3(64), lds, st, m, t, d, cm, cd, mode, dump); }
+
+#if defined(TPK_tp)
+TP_KERNEL(tp, false, false, false, false, false, true, false)
+#elif defined(TPK_tp_cg)
+TP_KERNEL(tp_cg, false, false, false, true, false, true, false)
+#elif defined(TPK_tp_pgs)
+TP_KERNEL(tp_pgs, false, false, false, false, true, false, true)
+#elif defined(TPK_tp_rk4)
+TP_KERNEL(tp_rk4, false, false, true, false, false, false, false)
+#elif defined(TPK_tp_rk4_cg)
+TP_KERNEL(tp_rk4_cg, false, false, true, true, false, false, false)
+#elif defined(TPK_tp_rk4_pgs)
+TP_KERNEL(tp_rk4_pgs, false, false, true, false, true, false, true)
+#elif defined(TPK_tp_full)
+TP_KERNEL(tp_full, false, true, false, false, false, false, false)
+#elif defined(TPK_tp_col)
+// kinematics + geom frames + broadphase, tree-parallel layout (physics_tp.h::tp_collide_prep)
+__global__ __launch_bounds__(64) void k_tp_col(DevModel m, TpModel t, DevData d, ColModel cm, ColData cd) {
+  extern __shared__ double tpg_dyn[];  // geom frames of the two environments
+  tp_collide_prep(m, t, d, cm, cd, tpg_dyn);
+}
+void bs_launch_tp_col(dim3 g, size_t lds, hipStream_t st, const DevModel& m, const TpModel& t, const DevData& d,
+                      const ColModel& cm, const ColData& cd) {
+  hipLaunchKernelGGL(k_tp_col, g, dim3(64), lds, st, m, t, d, cm, cd);
+}
+#elif defined(TPK_tpc)
+TPC_KERNEL(tpc, false, false)
+#elif defined(TPK_tpc_cg)
+TPC_KERNEL(tpc_cg, true, false)
+#else
+#error "compile with -DTPK_<kernel name> (see the Makefile)"
+#endif
