@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define BS_VERSION 100
+#define BS_VERSION 200
 
 typedef enum bs_status {
   BS_OK = 0,
@@ -131,8 +131,24 @@ int bs_set_stream(bs_sim *s, void *hip_stream, int use_own_stream);
 int bs_step(bs_sim *s, int n_steps);
 /* Replaces MjSim.forward() = mj_forward. */
 int bs_forward(bs_sim *s);
-/* Replaces MjSim.reset() = mj_resetData; env_mask (host, n_envs bytes, nullable = all). */
+/* Replaces MjSim.reset() = mj_resetData; env_mask (host, n_envs bytes, nullable = all).  The mask is
+ * staged through buffers the sim owns: no allocation and no wait for the device per call. */
 int bs_reset(bs_sim *s, const uint8_t *env_mask);
+/* The same with the mask already in device memory of the sim's GPU (n_envs bytes, non-zero = reset):
+ * one kernel on the sim's stream, for rollout loops that compute `done` on the device (no mujoco-py
+ * counterpart: there one MjSim is one environment). */
+int bs_reset_device_mask(bs_sim *s, const uint8_t *dev_mask);
+
+/* Replaces MjSim.get_state() / set_state() (MjSimState: time, qpos, qvel, act, udd_state; reference call
+ * site of the sim object src/Mujoco_XML.py:341-345): the state as ONE device buffer [rows][ld] of the
+ * caller, rows = 1 + nq + 3 nv in the order time | qpos | qvel | qacc | qacc_warmstart (the last two make
+ * a restored run bit-identical: the solvers warm-start from qacc_warmstart), ld >= n_envs.  Copies are
+ * enqueued on the sim's stream. */
+int bs_state_rows(const bs_sim *s, int *rows);
+int bs_get_state(bs_sim *s, double *dev_buf, int64_t ld);
+int bs_set_state(bs_sim *s, const double *dev_buf, int64_t ld);
+/* The stream the sim's kernels are enqueued on (its own, or the one given to bs_set_stream). */
+int bs_get_stream(bs_sim *s, void **hip_stream);
 
 /* Zero-copy device view of a field (what sim.data.<field> wraps). shape/stride in elements. */
 int bs_get_ptr(bs_sim *s, int field_id, void **dev_ptr, int64_t shape[2], int64_t stride[2],
@@ -144,6 +160,9 @@ int bs_copy_field(bs_sim *s, int field_id, void *host, int direction);
 int bs_get_contacts(bs_sim *s, int64_t env, int32_t *geom1, int32_t *geom2, double *dist, int cap,
                     int *n);
 
+/* sim.data.contact[i].pos (3) and .frame (9, rows = normal, tangent1, tangent2) for one environment. */
+int bs_get_contact_geometry(bs_sim *s, int64_t env, double *pos, double *frame, int cap, int *n);
+
 /* Work-model counters of the collision stage since creation / last reset:
  * out[0] narrowphase pairs, out[1] MPR support iterations, out[2] contacts.  No mujoco-py
  * counterpart (mjData has no such counters); used by bench.py to report N_np and ncon. */
@@ -152,7 +171,8 @@ int bs_collision_stats(bs_sim *s, uint64_t out[3], int reset);
 int bs_sync(bs_sim *s);
 /* Runs one step stage by stage with HIP events between the stages and returns the elapsed
  * ms per stage: [0] position (A1-A4) [1] collision (A5-A6) [2] velocity+actuation+accel (A8-A10)
- * [3] constraints (A7+A11) [4] integrate (A12/A13).  Advances the state by one step. */
+ * [3] constraints (A7+A11) [4] integrate (A12/A13).  Advances the state by one step (Euler for a sim
+ * with contacts; RK4 with contacts returns BS_ERR_UNSUPPORTED). */
 int bs_stage_times(bs_sim *s, double *ms, int n);
 /* Times n_steps of bs_step with HIP events on the sim's stream; returns elapsed ms. */
 int bs_timed_steps(bs_sim *s, int n_steps, double *elapsed_ms);

@@ -601,7 +601,13 @@ static int model_image(bs_model* m, int device, const DeviceImage** out) {
   HIPCHK(hipSetDevice(device));
   void* blob = nullptr;
   HIPCHK(hipMalloc(&blob, pk.bytes.size()));
-  HIPCHK(hipMemcpy(blob, pk.bytes.data(), pk.bytes.size(), hipMemcpyHostToDevice));
+  {
+    const hipError_t ce = hipMemcpy(blob, pk.bytes.data(), pk.bytes.size(), hipMemcpyHostToDevice);
+    if (ce != hipSuccess) {
+      (void)hipFree(blob);
+      return fail(BS_ERR_HIP, "model upload (%zu bytes) failed: %s", pk.bytes.size(), hipGetErrorString(ce));
+    }
+  }
   for (auto& f : fix) *f.slot = (char*)blob + f.off;
   DeviceImage im;
   im.device = device; im.blob = blob; im.dm = dm; im.tp = tp; im.cm = cm;
@@ -639,8 +645,16 @@ struct bs_sim {
   FieldInfo fields[BS_F_COUNT];
   double* derived = nullptr;  // scratch for on-demand fields (xmat, geom_xpos, geom_xmat)
   size_t derived_rows = 0;
-  hipEvent_t ev[8];
+  hipEvent_t ev[8] = {};
   bool events = false;
+  // bs_reset with a host mask: pinned staging + device copy, allocated once (no malloc / sync per call);
+  // mask_ev marks the end of the last upload, so the staging buffer is not overwritten under it
+  uint8_t* mask_pinned = nullptr;
+  uint8_t* mask_dev = nullptr;
+  hipEvent_t mask_ev = nullptr;
+  bool mask_pending = false;
+  size_t serial_rows = 0;   // rows of the serial contact solver's buffers (allocated on first use)
+  void* sarena = nullptr;   // cJ / Hd / cW of the serial contact solver (ensure_serial_contact)
   // mixed-model batch: one child sim per model over a contiguous range of environments (each with
   // its own arenas, since row counts differ between models); all run on this sim's stream
   // two halves of a contact batch on two streams: kernels of different kinds overlap (both the
@@ -656,6 +670,38 @@ struct bs_sim {
     return fail(BS_ERR_UNSUPPORTED, what ": a mixed-model sim has one field set per model; use bs_sim_part")
 
 
+extern "C" int bs_sim_destroy(bs_sim* s);
+// size of one range of a split contact batch: a whole number of 64-environment blocks
+static inline long split_chunk(long n_envs, int np) { return (n_envs / np + 63) / 64 * 64; }
+// Jacobian rows, dense Hessian and PGS rows of the serial contact solver (k_c_dyn): 43 KB per
+// environment, so they are allocated when the serial dynamics kernel is first needed (sims on the
+// serial path: at creation; sims on the tree-parallel path: the first bs_forward / bs_stage_times)
+static int ensure_serial_contact(bs_sim* s) {
+  if (!s->contacts || s->sarena) return BS_OK;
+  const size_t nv = (size_t)s->dm.nv, nr = 4 * (size_t)s->cm.maxcon, nh = nv * (nv + 1) / 2, E = (size_t)s->E;
+  const bool pgs = s->dm.solver == 0;
+  const size_t rows = nr * nv + nr * 5 + nh + (pgs ? nr * nv : 0);
+  const hipError_t he = hipMalloc(&s->sarena, rows * E * sizeof(double));
+  if (he != hipSuccess) {
+    s->sarena = nullptr;
+    return fail(BS_ERR_NOMEM, "hipMalloc of %zu bytes for the serial contact solver failed: %s", rows * E * sizeof(double),
+                hipGetErrorString(he));
+  }
+  HIPCHK(hipMemsetAsync(s->sarena, 0, rows * E * sizeof(double), s->stream));
+  double* dp = (double*)s->sarena;
+  auto take = [&](size_t rows_) { double* q = dp; dp += rows_ * E; return q; };
+  ConData& k = s->kd;
+  k.cJ = take(nr * nv); k.cD = take(nr); k.caref = take(nr); k.cjar = take(nr); k.cjv = take(nr); k.cforce = take(nr);
+  k.Hd = take(nh);
+  k.cW = pgs ? take(nr * nv) : nullptr;
+  // dense Hessian in LDS when (nv(nv+1)/2 + nv) x 64 lanes x 8 B fits one CU's 160 KB
+  const size_t want = (nh + nv) * BS_BLOCK * sizeof(double);
+  if (want <= 160 * 1024 && getenv("BS_LDS_HESSIAN")) {  // opt-in: lowers occupancy to one wave per CU
+    if (bs_c_dyn_set_lds((int)want) == hipSuccess) s->hs_bytes = want;
+    else (void)hipGetLastError();
+  }
+  return BS_OK;
+}
 static inline dim3 grid_for(const bs_sim* s) { return dim3((unsigned)((s->n_envs + BS_BLOCK - 1) / BS_BLOCK)); }
 static inline dim3 grid_tp(const bs_sim* s) { return dim3((unsigned)((s->n_envs + 1) / 2)); }
 // narrowphase: flattened work items by default; BS_NARROW=ws selects the work-stealing variant
@@ -715,12 +761,12 @@ static void launch_step(bs_sim* s, int n_steps) {
       // range 0 on the sim's stream, the others on auxiliary streams, joined at the end
       const int np = s->split;
       DevData part[4];
-      const long chunk = (s->n_envs / np + 63) / 64 * 64;
+      const long chunk = split_chunk(s->n_envs, np);  // bs_sim_create made sure every range is non-empty
       for (int q = 0; q < np; q++) {
         part[q] = s->dd;
         part[q].env0 = q * chunk;
         part[q].range = q;
-        part[q].n_envs = q == np - 1 ? s->n_envs : (q + 1) * chunk;
+        part[q].n_envs = q == np - 1 || (q + 1) * chunk > s->n_envs ? s->n_envs : (q + 1) * chunk;
       }
       (void)hipEventRecord(s->fork_ev, s->stream);
       for (int q = 1; q < np; q++) (void)hipStreamWaitEvent(s->aux_stream[q - 1], s->fork_ev, 0);
@@ -800,16 +846,25 @@ extern "C" int bs_sim_create(const bs_model* const* models, int n_models, const 
 
   bs_sim* s = new bs_sim();
   s->model = model; s->dm = img->dm; s->tp = img->tp; s->device = device; s->n_envs = n_envs;
+  // every failure below goes through bs_sim_destroy, which tolerates a partially built sim
+#define HIPCHK_S(call)                                                                              \
+  do {                                                                                              \
+    hipError_t e_ = (call);                                                                         \
+    if (e_ != hipSuccess) {                                                                         \
+      bs_sim_destroy(s);                                                                            \
+      return fail(BS_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    }                                                                                               \
+  } while (0)
   const char* kv = getenv("BS_KERNEL");
   s->contacts = contacts;
   s->cm = img->cm;
   s->cm.maxcon = (opt && opt->max_contacts_per_env > 0) ? opt->max_contacts_per_env : 32;
   s->cm.maxcand = model->d.npair < 256 ? model->d.npair : 256;
-  // contact-free: every solver with either integrator; with contacts: Newton and CG with either integrator
+  // every solver with either integrator, with and without contacts (PGS with contacts: Euler)
+  const bool serial = kv && strcmp(kv, "serial") == 0;
   const bool tp_solver = model->d.solver == 2 || model->d.solver == 1;
-  s->use_tp = !contacts && model->tp_ok && !(kv && strcmp(kv, "serial") == 0);
-  s->use_tpc = contacts && tp_solver && model->tp_ok && s->cm.maxcon <= TP_LPE &&
-               !(kv && strcmp(kv, "serial") == 0);
+  s->use_tp = !contacts && model->tp_ok && !serial;
+  s->use_tpc = contacts && tp_solver && model->tp_ok && s->cm.maxcon <= TP_LPE && !serial;
   {
     const char* nk = getenv("BS_NARROW");
     s->narrow_ws = nk && strcmp(nk, "ws") == 0;
@@ -822,8 +877,8 @@ extern "C" int bs_sim_create(const bs_model* const* models, int n_models, const 
   s->E = (n_envs + 63) / 64 * 64;
   const DevModel& m = s->dm;
   const long E = s->E;
-  HIPCHK(hipSetDevice(device));
-  HIPCHK(hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking));
+  HIPCHK_S(hipSetDevice(device));
+  HIPCHK_S(hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking));
   s->stream = s->own_stream;
 
   // arena layout: all double rows, then the int rows
@@ -856,14 +911,15 @@ extern "C" int bs_sim_create(const bs_model* const* models, int n_models, const 
   s->derived_rows = (size_t)9 * nb + (size_t)12 * (m.ngeom > 0 ? m.ngeom : 1);
   const size_t dbl_bytes = (rows + s->derived_rows) * (size_t)E * sizeof(double);
   const size_t int_bytes = 3 * (size_t)E * sizeof(int);
-  s->arena_bytes = dbl_bytes + int_bytes;
+  s->arena_bytes = dbl_bytes + int_bytes + (size_t)E;  // + the device copy of bs_reset's mask
   hipError_t he = hipMalloc(&s->arena, s->arena_bytes);
   if (he != hipSuccess) {
-    (void)hipStreamDestroy(s->own_stream);
-    delete s;
-    return fail(BS_ERR_NOMEM, "bs_sim_create: hipMalloc of %zu bytes failed: %s", s->arena_bytes, hipGetErrorString(he));
+    const size_t want = s->arena_bytes;
+    s->arena = nullptr;
+    bs_sim_destroy(s);
+    return fail(BS_ERR_NOMEM, "bs_sim_create: hipMalloc of %zu bytes failed: %s", want, hipGetErrorString(he));
   }
-  HIPCHK(hipMemset(s->arena, 0, s->arena_bytes));
+  HIPCHK_S(hipMemset(s->arena, 0, s->arena_bytes));
   double* base = (double*)s->arena;
   size_t r = 0;
   for (auto& sl : slots) {
@@ -877,6 +933,7 @@ extern "C" int bs_sim_create(const bs_model* const* models, int n_models, const 
   s->fields[BS_F_GEOM_XMAT] = {s->derived + ((size_t)9 * nb + 3 * (size_t)m.ngeom) * E, 9 * m.ngeom, false};
   int* ibase = (int*)((char*)s->arena + dbl_bytes);
   d.solver_iter = ibase; d.warning = ibase + E; d.nefc = ibase + 2 * E;
+  s->mask_dev = (uint8_t*)(ibase + 3 * E);
   s->fields[BS_F_SOLVER_ITER] = {d.solver_iter, 1, true};
   s->fields[BS_F_WARNING] = {d.warning, 1, true};
   s->fields[BS_F_NEFC] = {d.nefc, 1, true};
@@ -885,29 +942,29 @@ extern "C" int bs_sim_create(const bs_model* const* models, int n_models, const 
   s->cd.geom_xpos = (double*)s->fields[BS_F_GEOM_XPOS].ptr;
   s->cd.geom_xmat = (double*)s->fields[BS_F_GEOM_XMAT].ptr;
   if (contacts) {
-    const size_t mc = (size_t)s->cm.maxcand, mk = (size_t)s->cm.maxcon, nr = 4 * mk, nh = (size_t)nv * (nv + 1) / 2;
-    const size_t drows = mc * 7 + mk * 13 + nr * nv + nr * 5 + nh + (model->d.solver == 0 ? nr * nv : 0);
+    // candidate / contact lists and the narrowphase work list; the serial solver's Jacobian rows and
+    // dense Hessian (43 KB per environment) are allocated by ensure_serial_contact() only when the
+    // serial dynamics kernel is going to run
+    const size_t mc = (size_t)s->cm.maxcand, mk = (size_t)s->cm.maxcon;
+    const size_t drows = mc * 7 + mk * 13;
     const size_t irows = 1 + mc * 2 + 1 + mk + 1 + mk;
     const size_t nstat = BS_STAT_ITEMS + 4 * BS_NSUB;                 // counters (8 bytes each)
     const size_t nitems = mc * ((size_t)E + 4 * 2 * BS_NSUB);         // narrowphase work list, 4 ranges at most
     const size_t bytes = drows * E * sizeof(double) + irows * E * sizeof(int) + 16 + nstat * 8 + nitems * sizeof(int);
     he = hipMalloc(&s->carena, bytes);
     if (he != hipSuccess) {
-      (void)hipFree(s->arena); (void)hipStreamDestroy(s->own_stream);
-      delete s;
+      s->carena = nullptr;
+      bs_sim_destroy(s);
       return fail(BS_ERR_NOMEM, "bs_sim_create: hipMalloc of %zu bytes for the contact arena failed: %s", bytes,
                   hipGetErrorString(he));
     }
-    HIPCHK(hipMemset(s->carena, 0, bytes));
+    HIPCHK_S(hipMemset(s->carena, 0, bytes));
     double* dp = (double*)s->carena;
     auto take = [&](size_t rows_) { double* q = dp; dp += rows_ * (size_t)E; return q; };
     ColData& c = s->cd;
     ConData& k = s->kd;
     c.cand_dist = take(mc); c.cand_pos = take(3 * mc); c.cand_nrm = take(3 * mc);
     c.con_dist = take(mk); c.con_pos = take(3 * mk); c.con_frame = take(9 * mk);
-    k.cJ = take(nr * nv); k.cD = take(nr); k.caref = take(nr); k.cjar = take(nr); k.cjv = take(nr); k.cforce = take(nr);
-    k.Hd = take(nh);
-    k.cW = model->d.solver == 0 ? take(nr * nv) : nullptr;
     int* ip = (int*)dp;
     auto takei = [&](size_t rows_) { int* q = ip; ip += rows_ * (size_t)E; return q; };
     c.ncand = takei(1); c.cand_pair = takei(mc); c.cand_hit = takei(mc);
@@ -916,35 +973,39 @@ extern "C" int bs_sim_create(const bs_model* const* models, int n_models, const 
     c.stat = (unsigned long long*)(((uintptr_t)ip + 7) & ~(uintptr_t)7);
     c.items = (int*)(c.stat + nstat);
     s->fields[BS_F_NCON] = {c.ncon, 1, true};
-    // dense Hessian in LDS when (nv(nv+1)/2 + nv) x 64 lanes x 8 B fits one CU's 160 KB
-    const size_t want = (nh + (size_t)nv) * BS_BLOCK * sizeof(double);
-    if (want <= 160 * 1024 && getenv("BS_LDS_HESSIAN")) {  // opt-in: lowers occupancy to one wave per CU
-      if (bs_c_dyn_set_lds((int)want) == hipSuccess)
-        s->hs_bytes = want;
-      else
-        (void)hipGetLastError();
+    if (!s->use_tpc) {
+      const int rc2 = ensure_serial_contact(s);
+      if (rc2) { bs_sim_destroy(s); return rc2; }
     }
   } else {
     s->fields[BS_F_NCON] = {d.nefc, 0, true};  // zero rows: no contacts in this sim
   }
-  for (auto& ev : s->ev) HIPCHK(hipEventCreate(&ev));
+  for (auto& ev : s->ev) ev = nullptr;
   s->events = true;
+  for (auto& ev : s->ev) HIPCHK_S(hipEventCreate(&ev));
+  HIPCHK_S(hipEventCreateWithFlags(&s->mask_ev, hipEventDisableTiming));
+  HIPCHK_S(hipHostMalloc((void**)&s->mask_pinned, (size_t)E, hipHostMallocDefault));
   {
-    const char* sp = getenv("BS_SPLIT");  // ranges of a contact batch run on separate streams
+    // ranges of a contact batch run on separate streams; every range is a whole number of 64-env
+    // blocks and non-empty (the count is lowered until that holds)
+    const char* sp = getenv("BS_SPLIT");
     int np = sp ? atoi(sp) : (n_envs >= 16384 ? 2 : 1);
     np = np < 1 ? 1 : (np > 4 ? 4 : np);
-    s->split = s->use_tpc && n_envs >= 128 * np ? np : 1;
+    if (!s->use_tpc || s->dm.integrator == 1) np = 1;
+    while (np > 1 && (n_envs < 128L * np || split_chunk(n_envs, np) * (np - 1) >= n_envs)) np--;
+    s->split = np;
     if (s->split > 1) {
-      HIPCHK(hipEventCreateWithFlags(&s->fork_ev, hipEventDisableTiming));
+      HIPCHK_S(hipEventCreateWithFlags(&s->fork_ev, hipEventDisableTiming));
       for (int q = 0; q < s->split - 1; q++) {
-        HIPCHK(hipStreamCreateWithFlags(&s->aux_stream[q], hipStreamNonBlocking));
-        HIPCHK(hipEventCreateWithFlags(&s->join_ev[q], hipEventDisableTiming));
+        HIPCHK_S(hipStreamCreateWithFlags(&s->aux_stream[q], hipStreamNonBlocking));
+        HIPCHK_S(hipEventCreateWithFlags(&s->join_ev[q], hipEventDisableTiming));
       }
     }
   }
   bs_launch_reset(grid_for(s), s->stream, s->dm, s->dd, (const uint8_t*)nullptr);
-  HIPCHK(hipGetLastError());
-  HIPCHK(hipStreamSynchronize(s->stream));
+  HIPCHK_S(hipGetLastError());
+  HIPCHK_S(hipStreamSynchronize(s->stream));
+#undef HIPCHK_S
   *out = s;
   return BS_OK;
 }
@@ -958,14 +1019,19 @@ extern "C" int bs_sim_destroy(bs_sim* s) {
     bs_sim_destroy(c);
   }
   if (s->events)
-    for (auto& ev : s->ev) (void)hipEventDestroy(ev);
-  for (int q = 0; q < 3; q++)
+    for (auto& ev : s->ev)
+      if (ev) (void)hipEventDestroy(ev);
+  for (int q = 0; q < 3; q++) {
     if (s->aux_stream[q]) {
       (void)hipStreamSynchronize(s->aux_stream[q]);
       (void)hipStreamDestroy(s->aux_stream[q]);
-      (void)hipEventDestroy(s->join_ev[q]);
     }
+    if (s->join_ev[q]) (void)hipEventDestroy(s->join_ev[q]);
+  }
   if (s->fork_ev) (void)hipEventDestroy(s->fork_ev);
+  if (s->mask_ev) (void)hipEventDestroy(s->mask_ev);
+  if (s->mask_pinned) (void)hipHostFree(s->mask_pinned);
+  if (s->sarena) (void)hipFree(s->sarena);
   if (s->arena) (void)hipFree(s->arena);
   if (s->carena) (void)hipFree(s->carena);
   if (s->own_stream) (void)hipStreamDestroy(s->own_stream);
@@ -1019,9 +1085,11 @@ extern "C" int bs_forward(bs_sim* s) {
     }
     return BS_OK;
   }
-  if (s->contacts)
+  if (s->contacts) {
+    const int rc = ensure_serial_contact(s);  // bs_forward writes every intermediate: serial pipeline
+    if (rc) return rc;
     launch_contact_pass(s, 0, 0);
-  else if (s->use_tp && s->dm.solver == 2)
+  } else if (s->use_tp && s->dm.solver == 2)
     bs_launch_tp_full(grid_tp(s), 0, s->stream, s->dm, s->tp, s->dd, 1, 1, 2);
   else
     bs_launch_forward(grid_for(s), s->stream, s->dm, s->dd);
@@ -1039,17 +1107,36 @@ extern "C" int bs_reset(bs_sim* s, const uint8_t* env_mask) {
     }
     return BS_OK;
   }
-  uint8_t* dmask = nullptr;
+  const uint8_t* dmask = nullptr;
   if (env_mask) {
-    HIPCHK(hipMalloc((void**)&dmask, (size_t)s->n_envs));
-    HIPCHK(hipMemcpyAsync(dmask, env_mask, (size_t)s->n_envs, hipMemcpyHostToDevice, s->stream));
+    // staged through the sim's pinned buffer: nothing is allocated and the host does not wait for
+    // the device (only for the previous upload, if it has not left the staging buffer yet)
+    if (s->mask_pending) HIPCHK(hipEventSynchronize(s->mask_ev));
+    memcpy(s->mask_pinned, env_mask, (size_t)s->n_envs);
+    HIPCHK(hipMemcpyAsync(s->mask_dev, s->mask_pinned, (size_t)s->n_envs, hipMemcpyHostToDevice, s->stream));
+    HIPCHK(hipEventRecord(s->mask_ev, s->stream));
+    s->mask_pending = true;
+    dmask = s->mask_dev;
   }
-  bs_launch_reset(grid_for(s), s->stream, s->dm, s->dd, (const uint8_t*)dmask);
+  bs_launch_reset(grid_for(s), s->stream, s->dm, s->dd, dmask);
   HIPCHK(hipGetLastError());
-  if (dmask) {
-    HIPCHK(hipStreamSynchronize(s->stream));
-    HIPCHK(hipFree(dmask));
+  return BS_OK;
+}
+
+// mj_resetData for the environments whose byte in `dev_mask` (device memory, n_envs bytes of the
+// sim's GPU) is non-zero: one kernel on the sim's stream, no host involvement.
+extern "C" int bs_reset_device_mask(bs_sim* s, const uint8_t* dev_mask) {
+  if (!s || !dev_mask) return fail(BS_ERR_INVALID, "bs_reset_device_mask: null argument");
+  HIPCHK(hipSetDevice(s->device));
+  if (!s->parts.empty()) {
+    for (size_t k = 0; k < s->parts.size(); k++) {
+      const int rc = bs_reset_device_mask(s->parts[k], dev_mask + s->part_start[k]);
+      if (rc) return rc;
+    }
+    return BS_OK;
   }
+  bs_launch_reset(grid_for(s), s->stream, s->dm, s->dd, dev_mask);
+  HIPCHK(hipGetLastError());
   return BS_OK;
 }
 
@@ -1134,6 +1221,72 @@ extern "C" int bs_get_contacts(bs_sim* s, int64_t env, int32_t* geom1, int32_t* 
   return BS_OK;
 }
 
+// sim.data.contact[i].pos / frame of one environment (rows of mjContact beyond bs_get_contacts)
+extern "C" int bs_get_contact_geometry(bs_sim* s, int64_t env, double* pos, double* frame, int cap, int* n) {
+  if (!s || !n) return fail(BS_ERR_INVALID, "bs_get_contact_geometry: null argument");
+  if (env < 0 || env >= s->n_envs) return fail(BS_ERR_INVALID, "bs_get_contact_geometry: env %lld out of range", (long long)env);
+  for (size_t k = 0; k < s->parts.size(); k++)
+    if (env >= s->part_start[k] && env < s->part_start[k] + s->parts[k]->n_envs)
+      return bs_get_contact_geometry(s->parts[k], env - s->part_start[k], pos, frame, cap, n);
+  *n = 0;
+  if (!s->contacts) return BS_OK;
+  if (cap < 0 || (cap > 0 && (!pos || !frame))) return fail(BS_ERR_INVALID, "bs_get_contact_geometry: null output");
+  HIPCHK(hipSetDevice(s->device));
+  HIPCHK(hipStreamSynchronize(s->stream));
+  int nc = 0;
+  HIPCHK(hipMemcpy(&nc, s->cd.ncon + env, sizeof(int), hipMemcpyDeviceToHost));
+  if (nc > s->cm.maxcon) nc = s->cm.maxcon;
+  *n = nc;
+  const int m = nc < cap ? nc : cap;
+  if (m <= 0) return BS_OK;
+  HIPCHK(hipMemcpy2D(pos, sizeof(double), s->cd.con_pos + env, (size_t)s->E * sizeof(double), sizeof(double),
+                     (size_t)3 * m, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy2D(frame, sizeof(double), s->cd.con_frame + env, (size_t)s->E * sizeof(double), sizeof(double),
+                     (size_t)9 * m, hipMemcpyDeviceToHost));
+  return BS_OK;
+}
+
+// ---- MjSimState: time | qpos | qvel | qacc | qacc_warmstart, everything a later step depends on
+// besides the inputs (ctrl, qfrc_applied), as one [rows][ld] device buffer of the caller
+static const int kStateFields[5] = {BS_F_TIME, BS_F_QPOS, BS_F_QVEL, BS_F_QACC, BS_F_QACC_WARMSTART};
+extern "C" int bs_state_rows(const bs_sim* s, int* rows) {
+  if (!s || !rows) return fail(BS_ERR_INVALID, "bs_state_rows: null argument");
+  NO_PARTS(s, "bs_state_rows");
+  int r = 0;
+  for (int f : kStateFields) r += s->fields[f].rows;
+  *rows = r;
+  return BS_OK;
+}
+static int state_copy(bs_sim* s, double* buf, int64_t ld, bool get) {
+  if (!s || !buf) return fail(BS_ERR_INVALID, "bs_get_state / bs_set_state: null argument");
+  NO_PARTS(s, "bs_get_state / bs_set_state");
+  if (ld < s->n_envs) return fail(BS_ERR_INVALID, "bs_get_state / bs_set_state: ld %lld < n_envs %ld", (long long)ld, s->n_envs);
+  HIPCHK(hipSetDevice(s->device));
+  size_t row = 0;
+  for (int f : kStateFields) {
+    const FieldInfo& fi = s->fields[f];
+    double* b = buf + row * (size_t)ld;
+    if (get)
+      HIPCHK(hipMemcpy2DAsync(b, (size_t)ld * 8, fi.ptr, (size_t)s->E * 8, (size_t)s->n_envs * 8, (size_t)fi.rows,
+                              hipMemcpyDeviceToDevice, s->stream));
+    else
+      HIPCHK(hipMemcpy2DAsync(fi.ptr, (size_t)s->E * 8, b, (size_t)ld * 8, (size_t)s->n_envs * 8, (size_t)fi.rows,
+                              hipMemcpyDeviceToDevice, s->stream));
+    row += (size_t)fi.rows;
+  }
+  return BS_OK;
+}
+extern "C" int bs_get_state(bs_sim* s, double* dev_buf, int64_t ld) { return state_copy(s, dev_buf, ld, true); }
+extern "C" int bs_set_state(bs_sim* s, const double* dev_buf, int64_t ld) {
+  return state_copy(s, const_cast<double*>(dev_buf), ld, false);
+}
+
+extern "C" int bs_get_stream(bs_sim* s, void** hip_stream) {
+  if (!s || !hip_stream) return fail(BS_ERR_INVALID, "bs_get_stream: null argument");
+  *hip_stream = (void*)s->stream;
+  return BS_OK;
+}
+
 extern "C" int bs_collision_stats(bs_sim* s, uint64_t out[3], int reset) {
   if (!s || !out) return fail(BS_ERR_INVALID, "bs_collision_stats: null argument");
   out[0] = out[1] = out[2] = 0;
@@ -1176,6 +1329,10 @@ extern "C" int bs_stage_times(bs_sim* s, double* ms, int n) {
   NO_PARTS(s, "bs_stage_times");
   HIPCHK(hipSetDevice(s->device));
   if (s->contacts) {
+    if (s->dm.integrator == 1)
+      return fail(BS_ERR_UNSUPPORTED, "bs_stage_times: the staged step is an Euler step; not available for RK4 with contacts");
+    const int rc = ensure_serial_contact(s);
+    if (rc) return rc;
     const dim3 g = dim3((unsigned)((s->n_envs + BS_BLOCK - 1) / BS_BLOCK));
     HIPCHK(hipEventRecord(s->ev[0], s->stream));
     bs_launch_c_pos(g, s->stream, s->dm, s->dd, s->cd, 1);

@@ -1775,9 +1775,13 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
               if (a < c.dd) { AT(d.qM, adr + a) = Mr.r[a]; AT(d.qLD, adr + a) = LM.R.r[a]; }
             AT(d.qLDiagInv, j) = LM.dinv;
             const int fr = t.lane[TPI_FRIC_ROW * TP_LPE + l], lr = t.lane[TPI_LIM_ROW * TP_LPE + l];
-            if (fr >= 0) AT(d.efc_force, fr) = frc[0];
-            if (lr >= 0) { AT(d.efc_force, lr) = frc[1]; AT(d.efc_force, lr + 1) = frc[2]; }
-            if (eq_own >= 0) AT(d.efc_force, eq_own) = frc[3];
+            if (fr >= 0) { AT(d.efc_force, fr) = frc[0]; AT(d.efc_D, fr) = r.Df; AT(d.efc_aref, fr) = r.aref_f; }
+            if (lr >= 0) {
+              AT(d.efc_force, lr) = frc[1]; AT(d.efc_force, lr + 1) = frc[2];
+              AT(d.efc_D, lr) = r.Dl0; AT(d.efc_D, lr + 1) = r.Dl1;
+              AT(d.efc_aref, lr) = r.aref_l0; AT(d.efc_aref, lr + 1) = r.aref_l1;
+            }
+            if (eq_own >= 0) { AT(d.efc_force, eq_own) = frc[3]; AT(d.efc_D, eq_own) = r.De; AT(d.efc_aref, eq_own) = r.aref_e; }
           }
         }
       }

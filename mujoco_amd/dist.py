@@ -55,6 +55,12 @@ class ObsGather:
         # reused: wait() above has ordered this stream after the collective that read it last
         local = self.local
         self.sim.pack_obs(local)
+        # the collective is ordered after torch's current stream: if the sim runs on another stream
+        # (use_torch_stream=False, or the caller switched streams), make the current stream wait for it
+        cur = torch.cuda.current_stream(local.device)
+        sh = self.sim.stream_handle()
+        if sh != cur.cuda_stream:
+            cur.wait_stream(torch.cuda.ExternalStream(sh, device=local.device))
         if not overlap:
             return all_gather_packed(local, self.world, self.group, self.out)
         self._local = local  # kept alive until the collective has read it

@@ -8,7 +8,7 @@ everything here is this build's definition, kept deliberately small:
   clamped to their ctrlrange, held for `frame_skip` physics steps (one control period);
 * reward = `-||qpos[actuated joints] - action||^2` (the placeholder of SURVEY.md §8d config 5);
 * an episode ends after `episode_steps` control periods or when `mj_check*` reset the environment
-  (`warning != 0`); finished environments are reset in place — all on the device, through the
+  (`warning & 7 != 0`); finished environments are reset in place — all on the device, through the
   zero-copy views of the library's arrays, so a rollout never synchronises with the host.
 
 With `world > 1` (one process per GPU) `step` also returns the all-gathered `[world * n_envs, ...]`
@@ -45,20 +45,15 @@ class HandVecEnv:
         return torch.cat([d.qpos, d.qvel], dim=1).to(torch.float32)
 
     def _reset_where(self, mask):
-        """mj_resetData for the environments in `mask` (device bool [n_envs]), optionally with uniform
-        noise on qpos inside the joint ranges."""
+        """mj_resetData for the environments in `mask` (device bool [n_envs]): one library kernel
+        (bs_reset_device_mask: state, inputs, time and warning flags of the masked environments),
+        optionally followed by uniform noise on qpos inside the joint ranges."""
         d = self.sim.data
-        q = self.qpos0.expand(self.n_envs, -1)
+        self.sim.reset(mask)
         if self.reset_noise > 0:
-            u = torch.rand((self.n_envs, self.qpos0.numel()), generator=self.gen, device=q.device, dtype=q.dtype)
-            q = torch.minimum(torch.maximum(q + self.reset_noise * (u - 0.5) * (self.jnt_hi - self.jnt_lo), self.jnt_lo), self.jnt_hi)
-        keep = (~mask).unsqueeze(1)
-        d.qpos.copy_(torch.where(keep, d.qpos, q))
-        for name in ("qvel", "qacc", "qacc_warmstart", "qfrc_applied", "ctrl"):
-            v = getattr(d, name)
-            v.mul_(keep.to(v.dtype))
-        d.time.mul_((~mask).to(d.time.dtype))
-        d.warning.mul_((~mask).to(d.warning.dtype))
+            u = torch.rand((self.n_envs, self.qpos0.numel()), generator=self.gen, device=mask.device, dtype=d.qpos.dtype)
+            q = torch.minimum(torch.maximum(self.qpos0 + self.reset_noise * (u - 0.5) * (self.jnt_hi - self.jnt_lo), self.jnt_lo), self.jnt_hi)
+            d.qpos.copy_(torch.where(mask.unsqueeze(1), q, d.qpos))
         self.t.mul_((~mask).to(self.t.dtype))
 
     def reset(self):
@@ -76,10 +71,14 @@ class HandVecEnv:
         err = d.qpos[:, self.act_joint] - a
         reward = -(err * err).sum(dim=1).to(torch.float32)
         self.t += 1
-        failed = d.warning != 0
+        # bits 0-2: mj_checkPos / Vel / Acc reset the environment; bit 3 (value 8) only says that the
+        # contact or candidate list overflowed (the step went on with a truncated list): reported, not an episode end
+        failed = (d.warning & 7) != 0
+        overflow = (d.warning & 8) != 0
+        d.warning.bitwise_and_(7)
         done = failed | (self.t >= self.episode_steps)
         obs = self._obs()
-        info = {"terminal_obs": obs, "failed": failed}
+        info = {"terminal_obs": obs, "failed": failed, "contact_overflow": overflow}
         self._reset_where(done)
         obs = torch.where(done.unsqueeze(1), self._obs(), obs)
         if self.world > 1:

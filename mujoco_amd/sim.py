@@ -18,6 +18,7 @@ from . import _abi
 from ._abi import BatchSimError  # noqa: F401
 
 MjSimState = namedtuple("MjSimState", "time qpos qvel act udd_state")
+MjContact = namedtuple("MjContact", "geom1 geom2 dist pos frame")
 
 # field -> trailing shape (as a function of the model) for reshaping [E, rows]
 _SHAPES = {
@@ -153,6 +154,30 @@ class BatchData:
         _abi.check(_abi.lib().bs_get_contacts(self._sim._h, int(env), g1, g2, dist, cap, C.byref(n)))
         return [(g1[i], g2[i], dist[i]) for i in range(min(n.value, cap))]
 
+    @property
+    def contact(self):
+        """mujoco-py's `sim.data.contact[i].geom1 / geom2 / dist / pos / frame` (single-environment sims;
+        for a batch use `contact_list(env)`): the first `ncon` entries of mjData.contact."""
+        if self._sim.n_envs != 1:
+            raise AttributeError("sim.data.contact is per environment: use sim.data.contact_list(env) on a batched sim")
+        return self.contact_list(0)
+
+    def contact_list(self, env=0, cap=64):
+        """List of `MjContact(geom1, geom2, dist, pos[3], frame[9])` of one environment."""
+        g1 = (C.c_int32 * cap)()
+        g2 = (C.c_int32 * cap)()
+        dist = (C.c_double * cap)()
+        pos = (C.c_double * (3 * cap))()
+        frame = (C.c_double * (9 * cap))()
+        n = C.c_int()
+        _abi.check(_abi.lib().bs_get_contacts(self._sim._h, int(env), g1, g2, dist, cap, C.byref(n)))
+        _abi.check(_abi.lib().bs_get_contact_geometry(self._sim._h, int(env), pos, frame, cap, C.byref(n)))
+        k = min(n.value, cap)
+        # device layout is [3 * maxcon][E]: row 3 i + q of the column is component q of contact i
+        P = np.array(pos[:3 * k]).reshape(k, 3)
+        F = np.array(frame[:9 * k]).reshape(k, 9)
+        return [MjContact(int(g1[i]), int(g2[i]), float(dist[i]), P[i], F[i]) for i in range(k)]
+
     def to_host(self, name):
         """Dense NumPy copy `[rows, n_envs]` of a field via bs_copy_field (synchronises)."""
         sim = self._sim
@@ -178,7 +203,7 @@ class BatchSim:
 
     def __init__(self, model, n_envs=1, device_id=0, nsubsteps=1, use_torch_stream=True, max_contacts=0):
         """`max_contacts`: cap of the contact list per environment (0 = the library's default, 32;
-        further contacts of an environment are dropped in geom-pair order and set warning bit 8)."""
+        further contacts of an environment are dropped in geom-pair order and set warning bit 3, value 8)."""
         if n_envs < 1:
             raise ValueError("n_envs must be >= 1")
         if max_contacts < 0:
@@ -231,8 +256,17 @@ class BatchSim:
         _abi.check(_abi.lib().bs_forward(self._h))
 
     def reset(self, env_mask=None):
+        """`MjSim.reset()`; `env_mask`: optional per-environment selection, a host array (staged by the
+        library, no allocation per call) or a device uint8 / bool tensor (one kernel, no host round trip)."""
         if env_mask is None:
             _abi.check(_abi.lib().bs_reset(self._h, None))
+        elif hasattr(env_mask, "is_cuda") and env_mask.is_cuda:
+            import torch
+            mk = env_mask.to(torch.uint8).contiguous()
+            if tuple(mk.shape) != (self.n_envs,):
+                raise ValueError("env_mask must have shape (n_envs,)")
+            _abi.check(_abi.lib().bs_reset_device_mask(self._h, C.c_void_p(mk.data_ptr())))
+            self._keep_mask = mk  # alive until the kernel has read it (stream order: freed memory is reused in order)
         else:
             mk = np.ascontiguousarray(np.asarray(env_mask).astype(np.uint8))
             if mk.shape != (self.n_envs,):
@@ -242,15 +276,59 @@ class BatchSim:
     def sync(self):
         _abi.check(_abi.lib().bs_sync(self._h))
 
+    def _state_rows(self):
+        r = C.c_int()
+        _abi.check(_abi.lib().bs_state_rows(self._h, C.byref(r)))
+        return r.value
+
     def get_state(self):
-        d = self.data
-        return MjSimState(d.time.clone(), d.qpos.clone(), d.qvel.clone(), None, {})
+        """`MjSim.get_state()`: MjSimState(time, qpos, qvel, act=None, udd_state) as views of ONE device
+        snapshot buffer (bs_get_state); `udd_state` carries `qacc_warmstart` and `qacc`, which make a
+        restored run bit-identical (the solvers warm-start from the previous acceleration)."""
+        import torch
+        m = self.model
+        buf = torch.empty((self._state_rows(), self.n_envs), dtype=torch.float64, device=f"cuda:{self.device_id}")
+        _abi.check(_abi.lib().bs_get_state(self._h, C.c_void_p(buf.data_ptr()), self.n_envs))
+        nq, nv = m.nq, m.nv
+        cut = [0, 1, 1 + nq, 1 + nq + nv, 1 + nq + 2 * nv, 1 + nq + 3 * nv]
+        t, q, v, a, w = [buf[cut[i]:cut[i + 1]].T for i in range(5)]
+        if self.n_envs == 1:
+            t, q, v, a, w = float(t[0, 0]), q[0], v[0], a[0], w[0]
+        else:
+            t = t[:, 0]
+        return MjSimState(t, q, v, None, {"qacc": a, "qacc_warmstart": w, "_packed": buf})
 
     def set_state(self, state):
-        d = self.data
-        d.time.copy_(state.time if hasattr(state.time, "shape") else d.time.new_full(d.time.shape, state.time))
-        d.qpos.copy_(state.qpos)
-        d.qvel.copy_(state.qvel)
+        """`MjSim.set_state(state)`; states without `udd_state["qacc_warmstart"]` (e.g. hand-made ones)
+        restore time / qpos / qvel only and leave the warm start as it is (mujoco-py's behaviour)."""
+        import torch
+        udd = state.udd_state or {}
+        buf = udd.get("_packed")
+        E, dev = self.n_envs, f"cuda:{self.device_id}"
+        if buf is None or tuple(buf.shape) != (self._state_rows(), E):
+            buf = torch.empty((self._state_rows(), E), dtype=torch.float64, device=dev)
+            _abi.check(_abi.lib().bs_get_state(self._h, C.c_void_p(buf.data_ptr()), E))
+        else:
+            buf = buf.clone()  # the caller may have edited the views
+        m = self.model
+        nq, nv = m.nq, m.nv
+        cut = [0, 1, 1 + nq, 1 + nq + nv, 1 + nq + 2 * nv, 1 + nq + 3 * nv]
+        parts = [state.time, state.qpos, state.qvel, udd.get("qacc"), udd.get("qacc_warmstart")]
+        for i, val in enumerate(parts):
+            if val is None:
+                continue
+            val = torch.as_tensor(val, dtype=torch.float64, device=dev)
+            rows = cut[i + 1] - cut[i]
+            val = val.reshape(E, rows) if val.numel() == E * rows else val.reshape(1, -1).expand(E, rows)
+            buf[cut[i]:cut[i + 1]].copy_(val.T)
+        _abi.check(_abi.lib().bs_set_state(self._h, C.c_void_p(buf.data_ptr()), E))
+        self._keep_state = buf  # alive until the copies have run
+
+    def stream_handle(self):
+        """The hipStream_t the sim's kernels are enqueued on (bs_get_stream)."""
+        h = C.c_void_p()
+        _abi.check(_abi.lib().bs_get_stream(self._h, C.byref(h)))
+        return h.value or 0
 
     def stage_times(self):
         ms = (C.c_double * 5)()
@@ -348,10 +426,17 @@ class MixedBatchSim(BatchSim):
         return [(g1[i], g2[i], dist[i]) for i in range(min(n.value, cap))]
 
     def get_state(self):
-        return [MjSimState(p.data.time.clone(), p.data.qpos.clone(), p.data.qvel.clone(), None, {}) for p in self.parts]
+        return [MjSimState(p.data.time.clone(), p.data.qpos.clone(), p.data.qvel.clone(), None,
+                           {"qacc": p.data.qacc.clone(), "qacc_warmstart": p.data.qacc_warmstart.clone()})
+                for p in self.parts]
 
     def set_state(self, states):
         for p, st in zip(self.parts, states):
             p.data.time.copy_(st.time)
             p.data.qpos.copy_(st.qpos)
             p.data.qvel.copy_(st.qvel)
+            udd = st.udd_state or {}
+            if "qacc" in udd:
+                p.data.qacc.copy_(udd["qacc"])
+            if "qacc_warmstart" in udd:
+                p.data.qacc_warmstart.copy_(udd["qacc_warmstart"])

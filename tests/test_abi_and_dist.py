@@ -20,7 +20,7 @@ def test_header_symbols_exported():
     L = _abi.lib()
     for s in declared:
         assert hasattr(L, s), s
-    assert L.bs_version() == 100
+    assert L.bs_version() == 200
     # field enum order in the header == python table
     enum = re.search(r"typedef enum bs_field \{(.*?)\} bs_field;", hdr, re.S).group(1)
     enum = re.sub(r"/\*.*?\*/", "", enum, flags=re.S)

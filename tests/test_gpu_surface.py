@@ -1,0 +1,216 @@
+"""GPU tests of the mujoco-py-shaped surface and of the exported
+intermediates (rows A2 / A7) against the oracle, through the C-ABI.  PARITY UNPINNED vs MuJoCo
+2.1.0: the oracle is the in-repo restatement (oracle/oracle.h)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _efc_row_map(m, s):
+    """Oracle efc rows (active rows only, efc order) -> row index in the device's fixed layout
+    (active equalities | dofs with frictionloss | lower, upper limit of every limited joint)."""
+    eq_ids = [e for e in range(m.neq) if m.eq_active[e]]
+    fric = [i for i in range(m.nv) if m.dof_frictionloss[i] > 0]
+    lim = [j for j in range(m.njnt) if m.jnt_limited[j]]
+    typ, ids, J = s.efc("type"), s.efc("id"), s.efc("J")
+    out = []
+    for i in range(len(typ)):
+        if typ[i] == 0:
+            out.append(eq_ids.index(ids[i]))
+        elif typ[i] == 1:
+            out.append(len(eq_ids) + fric.index(ids[i]))
+        elif typ[i] == 3:
+            side = 0 if J[i, ids[i]] > 0 else 1
+            out.append(len(eq_ids) + len(fric) + 2 * lim.index(ids[i]) + side)
+        else:
+            out.append(-1)  # contact rows: not part of the fixed layout
+    return np.array(out)
+
+
+@pytest.mark.parametrize("kernel", ["tp", "serial"])
+def test_exported_intermediates_vs_oracle(hand_model, kernel, monkeypatch):
+    """A2 / A7 / A8 intermediates that bs_forward exports and round 1 never compared: subtree_com,
+    cinert, cdof, cvel, xipos, xanchor, xaxis, efc_D, efc_aref, efc_force, qfrc_constraint."""
+    import torch
+    from mujoco_amd import BatchSim, workload
+    from oracle import OracleSim
+    monkeypatch.setenv("BS_KERNEL", kernel)
+    m = workload.contact_free(hand_model)
+    E = 96
+    q, v = workload.config2_state(m, E, seed=21)
+    v = np.random.default_rng(3).normal(size=v.shape) * 0.5
+    c = workload.config2_ctrl(m, E, seed=21)
+    q[:, 3] = m.jnt_range[3, 0] + 0.002   # inside the limit margin: active limit rows
+    q[::2, 9] = m.jnt_range[9, 1] - 0.004
+    sim = BatchSim(m, n_envs=E)
+    monkeypatch.delenv("BS_KERNEL")
+    sim.data.qpos.copy_(torch.as_tensor(q)); sim.data.qvel.copy_(torch.as_tensor(v)); sim.data.ctrl.copy_(torch.as_tensor(c))
+    sim.forward(); sim.sync()
+    got = {f: getattr(sim.data, f).cpu().numpy() for f in
+           ("rootcom", "cinert", "cdof", "cvel", "xipos", "xanchor", "xaxis", "efc_D", "efc_aref", "efc_force",
+            "qfrc_constraint", "nefc", "qfrc_passive", "qfrc_actuator", "qfrc_smooth")}
+    root = int(m.body_rootid[m.nbody - 1])
+    for e in range(0, E, 7):
+        s = OracleSim(m)
+        s.qpos[:] = q[e]; s.qvel[:] = v[e]; s.ctrl[:] = c[e]
+        s.forward()
+        assert np.abs(got["rootcom"][e][root] - s.subtree_com[root]).max() <= 1e-12
+        for f, tol in (("cinert", 1e-12), ("cdof", 1e-12), ("cvel", 1e-11), ("xipos", 1e-12), ("xanchor", 1e-12), ("xaxis", 1e-12)):
+            ref = getattr(s, f)
+            assert np.abs(got[f][e] - ref).max() <= tol * max(1.0, np.abs(ref).max()), (f, e)
+        for f in ("qfrc_passive", "qfrc_actuator", "qfrc_smooth"):
+            assert np.abs(got[f][e] - getattr(s, f)).max() <= 1e-12 * max(1.0, np.abs(getattr(s, f)).max()), (f, e)
+        rows = _efc_row_map(m, s)
+        assert (rows >= 0).all() and got["nefc"][e] == s.nefc == len(rows)
+        assert s.nefc > 25  # limit rows are active
+        for f, tol in (("efc_D", 1e-12), ("efc_aref", 1e-10), ("efc_force", 1e-8)):
+            ref = s.efc(f[4:])
+            dev = got[f][e][rows]
+            assert np.abs(dev - ref).max() <= tol * max(1.0, np.abs(ref).max()), (f, e, np.abs(dev - ref).max())
+        inactive = np.setdiff1d(np.arange(got["efc_D"].shape[1]), rows)
+        assert (got["efc_D"][e][inactive] == 0).all()
+        assert np.abs(got["qfrc_constraint"][e] - s.qfrc_constraint).max() <= 1e-8 * max(1.0, np.abs(s.qfrc_constraint).max())
+
+
+@pytest.mark.parametrize("contacts", [False, True])
+def test_state_round_trip_bit_exact(hand_model, contacts):
+    """MjSimState (A15): 100 steps -> get_state -> 100 steps -> set_state -> 100 steps gives the same
+    bits as the first continuation (qacc_warmstart is part of the snapshot), with and without contacts;
+    a state without the warm start restores time/qpos/qvel only."""
+    import torch
+    from mujoco_amd import BatchSim, workload
+    m = workload.with_ground_plane(hand_model, z=-0.05) if contacts else workload.contact_free(hand_model)
+    E = 130
+    q, v = workload.config2_state(m, E, seed=17)
+    sim = BatchSim(m, n_envs=E)
+    sim.data.qpos.copy_(torch.as_tensor(q))
+    sim.data.ctrl.copy_(torch.as_tensor(workload.config2_ctrl(m, E, seed=17)))
+    sim.step(100)
+    st = sim.get_state()
+    assert st.qpos.shape == (E, m.nq) and st.qvel.shape == (E, m.nv) and st.time.shape == (E,) and st.act is None
+    assert torch.equal(st.qpos, sim.data.qpos) and torch.equal(st.udd_state["qacc_warmstart"], sim.data.qacc_warmstart)
+    sim.step(100); sim.sync()
+    first = [getattr(sim.data, f).clone() for f in ("qpos", "qvel", "qacc", "time")]
+    if contacts:
+        assert int(sim.data.ncon.sum()) > 50
+    sim.set_state(st)
+    assert torch.equal(sim.data.qpos, st.qpos) and abs(float(sim.data.time[0]) - 100 * m.opt_timestep) < 1e-12
+    sim.step(100); sim.sync()
+    for a, f in zip(first, ("qpos", "qvel", "qacc", "time")):
+        assert torch.equal(a, getattr(sim.data, f)), f
+    # the snapshot is a copy: stepping did not change it; a hand-made state restores what it holds
+    from mujoco_amd.sim import MjSimState
+    sim.set_state(MjSimState(0.25, np.zeros(m.nq), np.zeros(m.nv), None, {}))
+    sim.sync()
+    assert float(sim.data.qpos.abs().max()) == 0 and float(sim.data.time.min()) == 0.25
+    one = BatchSim(m, n_envs=1)
+    one.step(3)
+    s1 = one.get_state()
+    assert s1.qpos.shape == (m.nq,) and isinstance(s1.time, float) and abs(s1.time - 3 * m.opt_timestep) < 1e-15
+    one.step(2); one.set_state(s1); one.sync()
+    assert torch.equal(one.data.qpos, s1.qpos)
+
+
+def test_contact_accessor_single_env(hand_model):
+    """`sim.data.contact[i].geom1 / geom2 / dist / pos / frame` for n_envs == 1 (mujoco-py's shape)."""
+    import torch
+    from mujoco_amd import BatchSim, workload
+    from oracle import OracleSim
+    m = workload.with_ground_plane(hand_model, z=-0.06)
+    qq = np.zeros(m.nq); qq[0] = -1.3
+    sim = BatchSim(m, n_envs=1)
+    sim.data.qpos.copy_(torch.as_tensor(qq))
+    sim.forward(); sim.sync()
+    s = OracleSim(m)
+    s.qpos[:] = qq
+    s.forward()
+    want = s.contacts()
+    con = sim.data.contact
+    assert len(con) == int(sim.data.ncon[0]) == len(want) > 0
+    for a, b in zip(con, want):
+        assert (a.geom1, a.geom2) == (b["geom1"], b["geom2"])
+        assert abs(a.dist - b["dist"]) < 1e-9
+        assert np.abs(a.pos - b["pos"]).max() < 1e-9 and np.abs(a.frame - b["frame"]).max() < 1e-9
+    two = BatchSim(m, n_envs=2)
+    with pytest.raises(AttributeError):
+        two.data.contact
+    assert two.data.contact_list(1) == []
+
+
+def test_device_mask_reset_and_split4_ragged(hand_model, monkeypatch):
+    """bs_reset_device_mask = bs_reset with the same mask; BS_SPLIT=4 with an environment count that
+    does not fill four 64-multiple ranges (520 envs) is bitwise what one range gives."""
+    import torch
+    from mujoco_amd import BatchSim, workload
+    m = hand_model.copy()
+    E = 520
+    q, v = workload.config2_state(m, E, seed=5)
+    c = workload.config2_ctrl(m, E, seed=5)
+    res = {}
+    for split in ("1", "4", "3"):
+        monkeypatch.setenv("BS_SPLIT", split)
+        sim = BatchSim(m, n_envs=E)
+        sim.data.qpos.copy_(torch.as_tensor(q)); sim.data.ctrl.copy_(torch.as_tensor(c))
+        sim.step(4); sim.sync()
+        res[split] = [getattr(sim.data, k).cpu().numpy().copy() for k in ("qpos", "qvel", "qacc", "ncon", "warning")]
+        if split != "1":
+            del sim
+        else:
+            keep = sim
+    monkeypatch.delenv("BS_SPLIT")
+    assert res["1"][3].sum() > 300 and (res["1"][4] == 0).all()
+    for split in ("4", "3"):
+        for a, b in zip(res["1"], res[split]):
+            assert np.array_equal(a, b)
+    # masked reset: host mask and device mask agree, untouched environments keep their bits
+    mask = np.zeros(E, dtype=np.uint8); mask[[0, 63, 64, 519]] = 1
+    other = BatchSim(m, n_envs=E)
+    other.set_state(keep.get_state())
+    other.data.ctrl.copy_(keep.data.ctrl)
+    keep.reset(mask)
+    other.reset(torch.as_tensor(mask, device=other.data.qpos.device).bool())
+    keep.sync(); other.sync()
+    for f in ("qpos", "qvel", "qacc", "qacc_warmstart", "ctrl", "time", "warning"):
+        assert torch.equal(getattr(keep.data, f), getattr(other.data, f)), f
+    assert float(keep.data.qpos[63].abs().max()) == 0 and float(keep.data.qpos[62].abs().max()) > 0
+    # two masked resets back to back reuse the staging buffer safely
+    m2 = np.zeros(E, dtype=np.uint8); m2[5] = 1
+    m3 = np.zeros(E, dtype=np.uint8); m3[6] = 1
+    keep.reset(m2); keep.reset(m3); keep.sync()
+    assert float(keep.data.qpos[5].abs().max()) == 0 and float(keep.data.qpos[6].abs().max()) == 0
+    assert float(keep.data.qpos[7].abs().max()) > 0
+
+
+def test_check_acc_paths_pinned(hand_model, monkeypatch):
+    """mj_checkAcc (A14) on one poisoned environment, every kernel family.  Contact-free kernels do what
+    mj_step does (reset, forward pass from the reset state, integrate: time = h afterwards); the
+    contact kernels reset and skip that step's integration (the next step recomputes the collision
+    from the reset pose), so time stays 0 — DESIGN.md §7 states this deviation; this test pins both."""
+    import torch
+    from mujoco_amd import BatchSim, workload
+    h = hand_model.opt_timestep
+    out = {}
+    for label, model, kern in (("cf_tp", workload.contact_free(hand_model), "tp"), ("cf_serial", workload.contact_free(hand_model), "serial"),
+                               ("con_tp", hand_model.copy(), "tp"), ("con_serial", hand_model.copy(), "serial")):
+        monkeypatch.setenv("BS_KERNEL", kern)
+        E = 8
+        q, v = workload.config2_state(model, E, seed=2)
+        sim = BatchSim(model, n_envs=E)
+        sim.data.qpos.copy_(torch.as_tensor(q))
+        sim.step(2)
+        sim.data.qfrc_applied[3, 4] = float("inf")  # bad qacc in environment 3 only
+        sim.step(1); sim.sync()
+        out[label] = (sim.data.warning.cpu().numpy().copy(), sim.data.time.cpu().numpy().copy(),
+                      sim.data.qpos.cpu().numpy().copy(), sim.data.qvel.cpu().numpy().copy())
+    monkeypatch.delenv("BS_KERNEL")
+    for label, (w, t, qp, qv) in out.items():
+        assert w[3] & 4 and (np.delete(w, 3) == 0).all(), label
+        assert np.isfinite(qp).all() and np.isfinite(qv).all(), label
+        assert abs(t[2] - 3 * h) < 1e-12
+        if label.startswith("cf"):
+            assert abs(t[3] - h) < 1e-15, label       # reset, forward, integrate (mj_step)
+        else:
+            assert t[3] == 0.0 and np.abs(qv[3]).max() == 0, label  # reset, integration skipped
+    assert np.allclose(out["cf_tp"][2][3], out["cf_serial"][2][3], atol=1e-12)
+    assert np.array_equal(out["con_tp"][2][3], out["con_serial"][2][3])
