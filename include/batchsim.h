@@ -139,6 +139,21 @@ int bs_reset(bs_sim *s, const uint8_t *env_mask);
  * counterpart: there one MjSim is one environment). */
 int bs_reset_device_mask(bs_sim *s, const uint8_t *dev_mask);
 
+/* Masked reset that ALLOCATES NOTHING.  No counterpart in the reference or in mujoco-py: it exists for
+ * callers that cannot call hipMalloc — code under HIP graph capture, tight serving / rollout loops,
+ * harnesses that forbid allocation.  Same result as bs_reset(s, env_mask) with a non-null mask, but the
+ * device copy of the mask is staged in a file-scope `static __device__` array of the library
+ * (BS_NOALLOC_MAX_ENVS bytes, held by every GPU the library runs on until the process ends) instead of
+ * memory the sim allocated; the array's device address is looked up once per device
+ * (hipGetSymbolAddress).  Sims with more than BS_NOALLOC_MAX_ENVS environments get BS_ERR_UNSUPPORTED.
+ * env_mask: host memory, n_envs bytes; if it is pinned / registered the call is fully asynchronous, a
+ * pageable buffer is waited for (stream synchronisation) before the call returns.  Calls no hipMalloc /
+ * hipFree / allocating routine.  Every call on a GPU shares that GPU's array: calls that overlap on one
+ * GPU (two sims on different streams, two host threads) race and must be serialised by the caller. */
+#define BS_NOALLOC_MAX_ENVS (1 << 19)
+#define BS_NOALLOC_MAX_DEVICES 64
+int bs_reset_noalloc(bs_sim *s, const uint8_t *env_mask);
+
 /* Replaces MjSim.get_state() / set_state() (MjSimState: time, qpos, qvel, act, udd_state; reference call
  * site of the sim object src/Mujoco_XML.py:341-345): the state as ONE device buffer [rows][ld] of the
  * caller, rows = 1 + nq + 3 nv in the order time | qpos | qvel | qacc | qacc_warmstart (the last two make

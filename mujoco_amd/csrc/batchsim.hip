@@ -8,6 +8,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -1136,6 +1137,57 @@ extern "C" int bs_reset_device_mask(bs_sim* s, const uint8_t* dev_mask) {
     return BS_OK;
   }
   bs_launch_reset(grid_for(s), s->stream, s->dm, s->dd, dev_mask);
+  HIPCHK(hipGetLastError());
+  return BS_OK;
+}
+
+// ---- allocation-free masked reset (include/batchsim.h: bs_reset_noalloc).  The device copy of the
+// mask lives in a file-scope __device__ array instead of memory the library allocates; each GPU holds
+// its own copy of the array at its own address, looked up once per device.
+static __device__ __align__(256) uint8_t scratch[BS_NOALLOC_MAX_ENVS];
+static uint8_t* g_scratch_ptr[BS_NOALLOC_MAX_DEVICES];  // device address of `scratch` per device, 0 = not looked up yet
+static std::mutex g_scratch_mu;
+static int scratch_on_device(int device, uint8_t** out) {
+  if (device < 0 || device >= BS_NOALLOC_MAX_DEVICES)
+    return fail(BS_ERR_UNSUPPORTED, "bs_reset_noalloc: device %d beyond the %d devices it keeps a scratch address for", device,
+                BS_NOALLOC_MAX_DEVICES);
+  std::lock_guard<std::mutex> lock(g_scratch_mu);
+  if (!g_scratch_ptr[device]) {
+    HIPCHK(hipSetDevice(device));  // the symbol resolves to the current device's copy
+    uint8_t* ptr = nullptr;
+    HIPCHK(hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch)));
+    if (!ptr) return fail(BS_ERR_HIP, "bs_reset_noalloc: hipGetSymbolAddress returned a null address");
+    g_scratch_ptr[device] = ptr;
+  }
+  *out = g_scratch_ptr[device];
+  return BS_OK;
+}
+
+extern "C" int bs_reset_noalloc(bs_sim* s, const uint8_t* env_mask) {
+  if (!s || !env_mask) return fail(BS_ERR_INVALID, "bs_reset_noalloc: null argument");
+  if (s->n_envs > BS_NOALLOC_MAX_ENVS)
+    return fail(BS_ERR_UNSUPPORTED, "bs_reset_noalloc: %ld environments exceed the static scratch of %d (use bs_reset)",
+                s->n_envs, BS_NOALLOC_MAX_ENVS);
+  uint8_t* ptr = nullptr;
+  const int rc = scratch_on_device(s->device, &ptr);
+  if (rc) return rc;
+  HIPCHK(hipSetDevice(s->device));
+  // pinned (or registered) host memory: the copy is asynchronous; pageable memory: wait until the
+  // copy has left the caller's buffer before returning
+  hipPointerAttribute_t at;
+  const bool pinned = hipPointerGetAttributes(&at, env_mask) == hipSuccess && at.type == hipMemoryTypeHost;
+  if (!pinned) (void)hipGetLastError();
+  // every byte the kernels read is overwritten here, so nothing of the previous call's mask survives
+  HIPCHK(hipMemcpyAsync(ptr, env_mask, (size_t)s->n_envs, hipMemcpyHostToDevice, s->stream));
+  if (!pinned) HIPCHK(hipStreamSynchronize(s->stream));
+  if (!s->parts.empty()) {
+    for (size_t k = 0; k < s->parts.size(); k++) {
+      bs_sim* c = s->parts[k];
+      bs_launch_reset(grid_for(c), s->stream, c->dm, c->dd, ptr + s->part_start[k]);
+    }
+  } else {
+    bs_launch_reset(grid_for(s), s->stream, s->dm, s->dd, ptr);
+  }
   HIPCHK(hipGetLastError());
   return BS_OK;
 }

@@ -273,6 +273,20 @@ class BatchSim:
                 raise ValueError("env_mask must have shape (n_envs,)")
             _abi.check(_abi.lib().bs_reset(self._h, mk.ctypes.data_as(C.POINTER(C.c_uint8))))
 
+    def reset_noalloc(self, env_mask):
+        """Masked reset through bs_reset_noalloc (the library's allocation-free entry point; at most
+        BS_NOALLOC_MAX_ENVS environments).  `env_mask`: host uint8 array or a pinned CPU tensor."""
+        if hasattr(env_mask, "data_ptr"):
+            if env_mask.is_cuda or env_mask.numel() != self.n_envs or env_mask.element_size() != 1 or not env_mask.is_contiguous():
+                raise ValueError("env_mask must be a contiguous 1-byte CPU tensor of n_envs elements")
+            ptr = C.c_void_p(env_mask.data_ptr())
+        else:
+            mk = np.ascontiguousarray(np.asarray(env_mask).astype(np.uint8))
+            if mk.shape != (self.n_envs,):
+                raise ValueError("env_mask must have shape (n_envs,)")
+            ptr = mk.ctypes.data_as(C.c_void_p)
+        _abi.check(_abi.lib().bs_reset_noalloc(self._h, ptr))
+
     def sync(self):
         _abi.check(_abi.lib().bs_sync(self._h))
 
