@@ -1,14 +1,24 @@
 #!/usr/bin/env python3
 """bench.py — env-steps/s of the batched physics step (BASELINE.json metric).
 
-Workload (N=1): BASELINE.json configs[1] — DexterousDynamos.xml joint-space only (contacts
-disabled), 4096 lockstep envs on one MI355X, random ctrl resampled every 50 steps, fp64.
-A "step" is one mj_step of the whole batch.  State and the ctrl bank are resident in HBM before
-the timed region.  N>1 (launched by torch.distributed.run): each rank steps its own 4096 envs
-(weak scaling, no traffic inside a step) and, once per control period (50 steps), all-gathers
-obs (qpos|qvel, fp32) + reward over RCCL for a centralised learner.
+`python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on rank 0.
 
-Prints ONE JSON line on rank 0.
+N = 1 (default):  headline = BASELINE.json configs[1] — DexterousDynamos.xml joint-space only (contacts
+  disabled), 4096 lockstep envs, random ctrl resampled every 50 steps, Euler + Newton, fp64 — with its
+  `roofline` (k_tp) and `cpu_baseline`; next to it the blocks
+    "contacts_65536":   configs[2] — STL-hull self-collision + ground plane, 65 536 envs (the north-star
+                        workload: value, ms_per_step, collision work model, histograms, roofline, cpu_baseline)
+    "contacts_131072":  configs[4]'s per-GPU share — the same with 131 072 envs and the per-control-period
+                        RCCL all-gather of obs/reward (one rank): the N = 1 point of the N > 1 curve below.
+N > 1 (launched by torch.distributed.run, one rank per GPU): configs[4]'s shape — every rank steps its own
+  131 072 envs with contacts (weak scaling, no traffic inside a step) and all-gathers obs (qpos|qvel fp32) +
+  reward once per control period (50 steps) over RCCL, overlapped with the next steps.  `value` is the
+  whole-job rate; compare it with N x the N = 1 run's contacts_131072.value.
+
+A "step" is one mj_step of the whole batch.  State and the ctrl bank are resident in HBM before the
+timed region.  Timing: W warm-up steps, then the K-step region is timed R = 5 times back to back (each
+bracketed by barrier + synchronize, MAX over ranks) and the MEDIAN is reported with `steps` = K, so a
+short K (the driver's 20) does not measure one launch's jitter.
 """
 import argparse
 import json
@@ -25,26 +35,28 @@ FLOP_PER_ENV_STEP = 36.0e3      # contact-free, Euler, Newton 
 BYTES_PER_ENV_STEP = 1.3e3      # compulsory HBM bytes per env-step
 FP64_PEAK_TFLOPS = 78.6         # MI355X fp64 vector == fp64 matrix peak (datasheet [EXT])
 CTRL_PERIOD = 50
+REPS = 5
 
 
-def pmc_traffic(kernel, section):
-    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC summary
-    (profiles/r01_pmc_summary.json, separate FETCH_SIZE / WRITE_SIZE passes of this same command):
-    (2 x FETCH_SIZE + WRITE_SIZE) KB, the gfx950 correction of MI355X_MICROARCH.md.  bench.py
-    cannot collect counters itself; None if the summary is missing."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")) as f:
-            k = json.load(f)[section][kernel]
-        return (2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0
-    except (OSError, KeyError, ValueError):
-        return None
+def pmc_traffic(section, kernels):
+    """HBM-side bytes per launch of `kernels` (summed) from the committed rocprofv3 PMC summary of this
+    round if present, else of round 1: (2 x FETCH_SIZE + WRITE_SIZE) KB, the gfx950 correction of
+    MI355X_MICROARCH.md.  bench.py cannot collect counters itself; None if the summary is missing."""
+    for name in ("r02_pmc_summary.json", "r01_pmc_summary.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                sec = json.load(f)[section]
+            return sum((2.0 * sec[k]["FETCH_SIZE"] + sec[k]["WRITE_SIZE"]) * 1024.0 for k in kernels), name
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None
 
 
-def cpu_baseline(model, seconds_budget=12.0):
-    """Oracle (CPU restatement, kind 'port') on this host: single thread, then all cores."""
+def cpu_baseline(model, seconds_budget=12.0, n_steps=1000):
+    """Oracle (CPU restatement, kind 'port') on this host, single thread, bounded sample."""
     from mujoco_amd import workload
     from oracle import OracleSim
-    n_envs, n_steps = 2048, 1000  # bounded by seconds_budget: about 12 s of single-thread work
+    n_envs = 2048
     q, v = workload.config2_state(model, n_envs, seed=1234)
     c = workload.config2_ctrl(model, n_envs, seed=1234)
     t0 = time.perf_counter()
@@ -86,9 +98,14 @@ def _pool_worker(args):
 
 
 def cpu_baseline_allcores(model_path, contacts=False):
+    """One oracle process per core of this job's CPU share.  The share is what the box grants the job
+    (OMP_NUM_THREADS, 16 per GPU on the MI355X pool, where os.cpu_count() reports the whole machine and
+    oversubscribing it gets the job killed); both numbers are reported."""
     import multiprocessing as mp
-    cores = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16") or 16), 16)
-    n_envs, n_steps = (40 if contacts else 400), 1000  # a few seconds per worker
+    share = os.environ.get("OMP_NUM_THREADS")
+    cores = min(os.cpu_count() or 1, int(share)) if share and share.isdigit() else (os.cpu_count() or 1)
+    cores = max(1, min(cores, 64))
+    n_envs, n_steps = (100, 200) if contacts else (400, 1000)   # a few seconds per worker
     ctx = mp.get_context("spawn")
     t0 = time.perf_counter()
     with ctx.Pool(cores) as pool:
@@ -96,9 +113,156 @@ def cpu_baseline_allcores(model_path, contacts=False):
     wall = time.perf_counter() - t0
     work = sum(r[0] for r in res)
     inner = max(r[1] for r in res)
-    return dict(value=work / inner, unit="env-steps/s", cores=cores, kind="port",
-                sample=f"{cores} processes x {n_envs} envs x {n_steps} steps (slowest worker {inner:.1f} s, "
-                       f"pool wall {wall:.1f} s incl. spawn)")
+    return dict(value=work / inner, unit="env-steps/s", cores=cores, host_cpu_count=os.cpu_count(), kind="port",
+                sample=f"{cores} processes (the job's CPU share; the host reports {os.cpu_count()} CPUs) x {n_envs} envs x "
+                       f"{n_steps} steps (slowest worker {inner:.1f} s, pool wall {wall:.1f} s incl. spawn)")
+
+
+def _hist(t, cap):
+    import torch
+    return torch.bincount(t.flatten().to(torch.int64).clamp_(0, cap), minlength=cap + 1).cpu().tolist()
+
+
+class Workload:
+    """One sim + ctrl bank + (optional) observation gather, timed the way the contract asks."""
+
+    def __init__(self, model, n_envs, local_rank, seed, gather_world=0, dist=None):
+        import torch
+        from mujoco_amd import BatchSim, workload
+        from mujoco_amd import dist as bdist
+        self.torch, self.dist = torch, dist
+        self.model, self.E = model, n_envs
+        self.dev = f"cuda:{local_rank}"
+        q, v = workload.config2_state(model, n_envs, seed=seed)
+        self.sim = BatchSim(model, n_envs=n_envs, device_id=local_rank)
+        self.sim.data.qpos.copy_(torch.as_tensor(q))
+        self.sim.data.qvel.copy_(torch.as_tensor(v))
+        self.n_bank = 8
+        self.bank = torch.as_tensor(np.stack([workload.config2_ctrl(model, n_envs, seed=seed, resample_idx=k)
+                                              for k in range(self.n_bank)])).to(self.dev)
+        self.gather = bdist.ObsGather(self.sim, gather_world) if gather_world else None
+        self.period = 0
+        self.launch_events = []
+
+    def run(self, nsteps, timed=False):
+        torch, sim = self.torch, self.sim
+        done = 0
+        while done < nsteps:
+            n = min(CTRL_PERIOD, nsteps - done)
+            sim.data.ctrl.copy_(self.bank[self.period % self.n_bank])
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                sim.step(n)
+                e1.record()
+                self.launch_events.append((e0, e1, n))
+            else:
+                sim.step(n)
+            if self.gather is not None:
+                self.gather.all_gather(overlap=True)  # under the next period's steps; fence() drains it
+            done += n
+            self.period += 1
+
+    def fence(self):
+        if self.gather is not None:
+            self.gather.wait()
+        self.torch.cuda.synchronize()
+        if self.dist is not None:
+            self.dist.barrier()
+            self.torch.cuda.synchronize()
+
+    def measure(self, steps, warmup, reps=REPS):
+        """-> dict(wall_s median over reps of the K-step region (MAX over ranks each), all walls, the
+        event-timed duration of every bs_step call of the timed regions)."""
+        torch = self.torch
+        self.run(warmup)
+        self.fence()
+        walls = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            self.run(steps, timed=True)
+            self.fence()
+            w = time.perf_counter() - t0
+            if self.dist is not None:
+                t = torch.tensor([w], dtype=torch.float64, device=self.dev)
+                self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+                w = float(t.item())
+            walls.append(w)
+        ev = [(a.elapsed_time(b), n) for a, b, n in self.launch_events]
+        self.launch_events = []
+        return dict(wall=float(np.median(walls)), walls=walls, launches=ev)
+
+    def state_stats(self):
+        d = self.sim.data
+        out = {"mean_solver_iter": float(d.solver_iter.double().mean().item()),
+               "mean_nefc": float(d.nefc.double().mean().item()),
+               "envs_with_warnings": int(((d.warning & 7) != 0).sum().item()),
+               "envs_with_contact_overflow": int(((d.warning & 8) != 0).sum().item()),
+               "solver_iter_hist": _hist(d.solver_iter, 12)}
+        if self.sim.model.npair > 0 and int(d.ncon.numel()) == self.E:
+            out["ncon_hist"] = _hist(d.ncon, 32)
+        return out
+
+    def collision_model(self, iters):
+        """Measured work model of SURVEY.md §8(d): N_np, MPR iterations, ncon per env-step over one control period."""
+        sim = self.sim
+        sim.collision_stats(reset=True)
+        sim.step(CTRL_PERIOD)
+        st = sim.collision_stats()
+        n = self.E * CTRL_PERIOD
+        c = {"narrow_pairs_per_env_step": st["narrow_pairs"] / n,
+             "mpr_iter_per_pair": st["mpr_iterations"] / max(1, st["narrow_pairs"]),
+             "ncon_per_env_step": st["contacts"] / n}
+        # F = 36k + 12k N_np + 6k ncon n_iter
+        flop = FLOP_PER_ENV_STEP + 12e3 * c["narrow_pairs_per_env_step"] + 6e3 * c["ncon_per_env_step"] * max(iters, 1.0)
+        return c, flop
+
+
+def roofline_block(launches, E, flop_env_step, kernel, traffic, traffic_src, note):
+    """achieved = algorithmic flop of the event-timed launches / their summed duration."""
+    ms = sum(t for t, _ in launches)
+    steps = sum(n for _, n in launches)
+    achieved = flop_env_step * E * steps / (ms * 1e-3) / 1e12
+    per_launch_steps = max(n for _, n in launches)
+    full = [t for t, n in launches if n == per_launch_steps]
+    return {"bound": "mfma", "bound_detail": "fp64 vector ALU (no MFMA instruction is used; the contract's two labels are hbm|mfma "
+                                             "and this is the compute one)",
+            "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS,
+            "traffic": traffic, "traffic_source": traffic_src, "kernel": kernel,
+            "launch_ms": float(np.mean(full)), "steps_per_launch": per_launch_steps, "launches_timed": len(launches),
+            "env_steps_per_launch": E * per_launch_steps, "flop_per_env_step": flop_env_step,
+            "algorithmic_hbm_GBps": BYTES_PER_ENV_STEP * E * steps / (ms * 1e-3) / 1e9, "note": note}
+
+
+def contacts_block(model_path, E, local_rank, seed, steps, warmup, world, dist, gather_world, with_cpu, label):
+    """configs[2] / configs[4]-share: contacts + ground plane at E envs per GPU."""
+    import torch
+    from mujoco_amd import Model, workload
+    model = workload.with_ground_plane(Model.load(model_path), z=-0.05)
+    w = Workload(model, E, local_rank, seed, gather_world=gather_world, dist=dist)
+    m = w.measure(steps, warmup)
+    stats = w.state_stats()
+    cstat, flop = w.collision_model(stats["mean_solver_iter"])
+    traffic, src = pmc_traffic("contacts_pmc_per_step" if E == 65536 else "none", ("k_tp_col", "k_c_narrow_list", "k_tpc"))
+    blk = {"value": E * world * steps / m["wall"], "unit": "env-steps/s", "ms_per_step": m["wall"] * 1e3 / steps,
+           "steps": steps, "reps": REPS, "wall_s_all_reps": m["walls"],
+           "config": {"workload": label, "n_envs_per_gpu": E, "n_envs_total": E * world, "ctrl_period": CTRL_PERIOD,
+                      "collective": ("RCCL all_gather obs[E,42]+reward fp32 per ctrl period, overlapped with the next steps"
+                                     if gather_world else "none"),
+                      "collision": cstat, **stats},
+           "roofline": roofline_block(m["launches"], E, flop, "k_tp_col + k_c_narrow_list + k_tpc (one step = 3 launches per range, "
+                                      "2 ranges on 2 streams)", traffic, src,
+                                      "flop model F = 36k + 12k N_np + 6k ncon n_iter with the measured N_np / ncon / n_iter of this run; "
+                                      "duration = HIP events around every bs_step call of the timed regions; traffic = per step, all three kernels")}
+    if with_cpu:
+        blk["cpu_baseline"] = cpu_baseline(model, seconds_budget=10.0, n_steps=200)
+        try:
+            blk["cpu_baseline_allcores"] = cpu_baseline_allcores(model_path, True)
+        except Exception as ex:
+            blk["cpu_baseline_allcores"] = {"error": repr(ex)}
+    del w
+    torch.cuda.empty_cache()
+    return blk
 
 
 def main_mixed(args):
@@ -149,7 +313,9 @@ def main_mixed(args):
         wall = time.perf_counter() - t0
         res[label] = {"value": 3 * per * args.steps / wall, "ms_per_step": wall * 1e3 / args.steps,
                       "mean_solver_iter": [float(p.data.solver_iter.double().mean().item()) for p in sim.parts],
-                      "envs_with_warnings": int(sum((p.data.warning != 0).sum().item() for p in sim.parts))}
+                      "solver_iter_hist": [_hist(p.data.solver_iter, 60) for p in sim.parts],
+                      "envs_with_warnings": int(sum(((p.data.warning & 7) != 0).sum().item() for p in sim.parts)),
+                      "envs_with_contact_overflow": int(sum(((p.data.warning & 8) != 0).sum().item() for p in sim.parts))}
         sim.close()
     out = {"metric": "env-steps/sec", "value": res["newton"]["value"], "unit": "env-steps/s", "n_gpus": 1,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["newton"]["ms_per_step"],
@@ -158,7 +324,7 @@ def main_mixed(args):
                                   "mixed-model batch, " + ("mesh self-collision on" if args.contacts else "joint-space only")
                                   + ", random ctrl resampled every 50 steps, Euler, Newton (value) and PGS",
                       "n_envs_per_model": per, "n_envs_total": 3 * per, "models": names},
-           "newton": res["newton"], "pgs": res["pgs"]}
+           "newton": res["newton"], "pgs": res["pgs"], "pgs_over_newton_time": res["newton"]["value"] / res["pgs"]["value"]}
     print(json.dumps(out), flush=True)
 
 
@@ -167,11 +333,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--envs", type=int, default=4096, help="environments per GPU")
+    ap.add_argument("--envs", type=int, default=0, help="environments per GPU (default: 4096 at N = 1, 131072 at N > 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-blocks", action="store_true", help="N = 1: only the headline workload (profiling runs)")
     ap.add_argument("--contacts", action="store_true",
-                    help="BASELINE.json configs[2] shape instead of configs[1]: mesh self-collision enabled "
-                         "(use with --envs 65536); not the default bench line")
+                    help="headline = BASELINE.json configs[2] shape (mesh self-collision + ground plane; use with --envs 65536) "
+                         "instead of configs[1]; implied at N > 1")
     ap.add_argument("--hull-verts", type=int, default=0,
                     help="with --contacts: OPT-IN hull simplification to at most this many vertices per hull "
                          "(changes the contact geometry; reported separately, never the parity configuration)")
@@ -182,10 +349,11 @@ def main():
                          "not the default bench line")
     args = ap.parse_args()
     if args.mixed:
+        args.envs = args.envs or 12288
         return main_mixed(args)
 
     import torch
-    from mujoco_amd import BatchSim, Model, workload
+    from mujoco_amd import Model, workload
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -197,11 +365,35 @@ def main():
     torch.cuda.set_device(local_rank)
     dist = None
     force_dist = bool(os.environ.get("BENCH_FORCE_DIST"))  # rehearsal of the N>1 code path with one rank
-    if world > 1 or force_dist:
+    multi = world > 1 or force_dist
+    if multi:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
 
     model_path = os.path.join(ROOT, "tests", "golden", "dexterous_model.npz")
+    seed = 1234 + 1000 * rank
+    plain = not (args.contacts or args.hull_verts or args.solver != "newton" or args.envs)
+
+    if multi and plain:
+        # ---- N > 1: configs[4]'s shape
+        E = 131072
+        blk = contacts_block(model_path, E, local_rank, seed, args.steps, args.warmup, world, dist, world, False,
+                             "BASELINE.json configs[4] shape: DexterousDynamos.xml with STL-hull mesh self-collision + a ground "
+                             "plane at z=-0.05 (the plane is this build's augmentation, not in the reference XML), 131072 envs per "
+                             "GPU, Euler + Newton, fp64, obs/reward all-gathered over RCCL every 50 steps")
+        if rank == 0:
+            out = {"metric": "env-steps/sec", "value": blk["value"], "unit": "env-steps/s", "n_gpus": world,
+                   "steps": args.steps, "warmup": args.warmup, "ms_per_step": blk["ms_per_step"],
+                   "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                   "config": blk["config"], "roofline": blk["roofline"], "reps": REPS, "wall_s_all_reps": blk["wall_s_all_reps"],
+                   "note": "N > 1 runs configs[4]'s shape; its N = 1 point is the block contacts_131072 of the N = 1 line "
+                           "(the N = 1 headline is configs[1], a different workload)"}
+            print(json.dumps(out), flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
+
+    # ---- headline workload (N = 1 default: configs[1]; flags select the variants)
     model = Model.load(model_path)
     if not args.contacts:
         model = workload.contact_free(model)
@@ -214,111 +406,39 @@ def main():
         from mujoco_amd.model import SOL_CG, SOL_PGS
         model = model.copy()
         model.opt_solver = SOL_CG if args.solver == "cg" else SOL_PGS
-    E = args.envs
-    seed = 1234 + 1000 * rank
-    q, v = workload.config2_state(model, E, seed=seed)
-    sim = BatchSim(model, n_envs=E, device_id=local_rank)
-    dev = f"cuda:{local_rank}"
-    sim.data.qpos.copy_(torch.as_tensor(q))
-    sim.data.qvel.copy_(torch.as_tensor(v))
-    n_bank = 8
-    bank = torch.as_tensor(np.stack([workload.config2_ctrl(model, E, seed=seed, resample_idx=k)
-                                     for k in range(n_bank)])).to(dev)
-
-    from mujoco_amd import dist as bdist
-    gather = bdist.ObsGather(sim, world) if (world > 1 or force_dist) else None
-
-    launch_events = []  # (start, end, steps) of every bs_step launch of the timed region, on the kernels' stream
-
-    def run(nsteps, start_period, timed=False):
-        done, period = 0, start_period
-        while done < nsteps:
-            n = min(CTRL_PERIOD, nsteps - done)
-            sim.data.ctrl.copy_(bank[period % n_bank])
-            if timed:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                sim.step(n)
-                e1.record()
-                launch_events.append((e0, e1, n))
-            else:
-                sim.step(n)
-            if gather is not None:
-                gather.all_gather(overlap=True)  # under the next period's steps; fence() drains it
-            done += n
-            period += 1
-        return period
-
-    def fence():
-        if gather is not None:
-            gather.wait()
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    period = run(args.warmup, 0)
-    fence()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    run(args.steps, period, timed=True)
-    ev1.record()
-    fence()
-    wall = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([wall], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall = float(t.item())
-    gpu_ms = ev0.elapsed_time(ev1)  # same stream as the kernels (BatchSim uses torch's current stream)
-    warn = int((sim.data.warning != 0).sum().item())
-    iters = float(sim.data.solver_iter.double().mean().item())
-    nefc = float(sim.data.nefc.double().mean().item())
-
-    # kernel timing: events around every bs_step launch of the timed region (the sim runs on torch's
-    # current stream, so the events sit on the kernels' stream); average per launch of CTRL_PERIOD steps
-    full = [(a.elapsed_time(b), n) for a, b, n in launch_events if n == CTRL_PERIOD] or \
-           [(a.elapsed_time(b) * CTRL_PERIOD / n, n) for a, b, n in launch_events]
-    k_ms = float(np.mean([t for t, _ in full]))
-    stage = sim.stage_times()
-    cstat = None
-    if args.contacts:
-        sim.collision_stats(reset=True)
-        sim.step(CTRL_PERIOD)
-        st = sim.collision_stats()
-        cstat = {"narrow_pairs_per_env_step": st["narrow_pairs"] / (E * CTRL_PERIOD),
-                 "mpr_iter_per_pair": st["mpr_iterations"] / max(1, st["narrow_pairs"]),
-                 "ncon_per_env_step": st["contacts"] / (E * CTRL_PERIOD)}
+    E = args.envs or 4096
+    w = Workload(model, E, local_rank, seed, gather_world=world if multi else 0, dist=dist)
+    m = w.measure(args.steps, args.warmup)
+    stats = w.state_stats()
+    try:
+        stage = w.sim.stage_times()
+    except Exception as ex:
+        stage = {"error": str(ex)}
+    cstat, flop_env_step = (w.collision_model(stats["mean_solver_iter"]) if args.contacts else (None, FLOP_PER_ENV_STEP))
 
     if rank == 0:
-        value = E * world * args.steps / wall
-        flop_env_step = FLOP_PER_ENV_STEP
-        if cstat:  # F = 36k + 12k N_np + 6k ncon n_iter
-            flop_env_step += 12e3 * cstat["narrow_pairs_per_env_step"] + 6e3 * cstat["ncon_per_env_step"] * max(iters, 1.0)
-        flops_launch = flop_env_step * E * CTRL_PERIOD
-        achieved = flops_launch / (k_ms * 1e-3) / 1e12
+        wall = m["wall"]
+        kern = "k_tp" if args.solver == "newton" else ("k_tp_cg" if args.solver == "cg" else "k_tp_pgs")
+        if args.contacts:
+            traffic, src = pmc_traffic("contacts_pmc_per_step" if E == 65536 and not args.hull_verts else "none",
+                                       ("k_tp_col", "k_c_narrow_list", "k_tpc"))
+            kern = "k_tp_col + k_c_narrow_list + " + {"newton": "k_tpc", "cg": "k_tpc_cg", "pgs": "k_tpc_pgs"}[args.solver]
+        else:
+            traffic, src = pmc_traffic("config1_pmc_per_launch" if E == 4096 and args.solver == "newton" else "none", ("k_tp",))
         out = {
-            "metric": "env-steps/sec", "value": value, "unit": "env-steps/s", "n_gpus": world,
+            "metric": "env-steps/sec", "value": E * world * args.steps / wall, "unit": "env-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall * 1e3 / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
-            "data": "synthetic",
+            "data": "synthetic", "reps": REPS, "wall_s_all_reps": m["walls"],
             "config": {"workload": "BASELINE.json configs[1]: DexterousDynamos.xml joint-space only "
                                    "(contacts disabled), lockstep envs, random ctrl resampled every 50 steps, "
                                    "Euler + Newton, fp64",
                        "n_envs_per_gpu": E, "n_envs_total": E * world, "ctrl_period": CTRL_PERIOD,
-                       "collective": "RCCL all_gather obs[E,42]+reward fp32 per ctrl period" if world > 1 else "none",
-                       "mean_solver_iter": iters, "mean_nefc": nefc, "envs_with_warnings": warn},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP64_PEAK_TFLOPS,
-                         "traffic": pmc_traffic("k_tp", "config1_pmc_per_launch") if not cstat else None,
-                         "kernel": "k_tp", "launch_ms": k_ms, "env_steps_per_launch": E * CTRL_PERIOD,
-                         "flop_per_env_step": flop_env_step,
-                         "note": "fp64 compute-bound path ('mfma' stands for the fp64 ALU roof: the contract allows "
-                                 "only hbm|mfma; no MFMA instruction is used): peak is the MI355X fp64 vector=matrix "
-                                 "rate; traffic = bytes/launch from the committed PMC summary (mostly register-spill "
-                                 "scratch, not state); algorithmic HBM rate would be "
-                                 f"{BYTES_PER_ENV_STEP * E * CTRL_PERIOD / (k_ms * 1e-3) / 1e9:.2f} GB/s of 8000"},
-            "gpu_event_ms_per_step": gpu_ms / args.steps,
+                       "collective": "RCCL all_gather obs[E,42]+reward fp32 per ctrl period" if multi else "none", **stats},
+            "roofline": roofline_block(m["launches"], E, flop_env_step, kern, traffic, src,
+                                       "duration = HIP events on the kernels' stream around every bs_step call of the timed regions "
+                                       "(one call = one launch of min(50, steps) steps); traffic = bytes per 50-step launch from the "
+                                       "committed PMC summary (prologue / epilogue state + outputs + spill scratch, not per-step traffic)"),
             "stage_ms_one_step": stage,
         }
         if cstat:
@@ -329,21 +449,43 @@ def main():
             if args.hull_verts > 0:
                 out["config"]["workload"] += f"; OPT-IN simplified hulls (<= {args.hull_verts} vertices each): NOT the parity geometry"
                 out["config"]["hull_verts"] = args.hull_verts
-            out["roofline"]["kernel"] = "k_tp_col+k_c_narrow_list+k_tpc (one step = 3 launches)"
         if args.solver != "newton":
             out["config"]["workload"] += f"; solver = {args.solver.upper()} (non-default)"
             out["config"]["solver"] = args.solver
-            out["roofline"]["traffic"] = None
-            if args.solver == "cg":
-                out["roofline"]["kernel"] = out["roofline"]["kernel"].replace("k_tpc", "k_tpc_cg") if cstat else "k_tp_cg"
-            else:
-                out["roofline"]["kernel"] = "serial kernels (k_c_dyn): PGS with contacts has no tree-parallel path" if cstat else "k_tp_pgs"
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(model)
+            out["cpu_baseline"] = cpu_baseline(model, n_steps=200 if args.contacts else 1000)
             try:
                 out["cpu_baseline_allcores"] = cpu_baseline_allcores(model_path, args.contacts)
             except Exception as ex:  # the pool is informational; the single-thread figure is the contract
                 out["cpu_baseline_allcores"] = {"error": repr(ex)}
+    del w
+    torch.cuda.empty_cache()
+    if plain and world == 1 and not args.no_extra_blocks:
+        # ---- the north-star workloads next to the headline
+        ksteps = min(args.steps, 200)
+        kwarm = min(args.warmup, 50)
+        own_pg = False
+        b2 = contacts_block(model_path, 65536, local_rank, seed, ksteps, kwarm, 1, None, 0, not args.no_cpu_baseline,
+                            "BASELINE.json configs[2]: DexterousDynamos.xml with STL-hull mesh self-collision + a ground plane at "
+                            "z=-0.05 (the plane is this build's augmentation, not in the reference XML), 65536 envs, Euler + Newton, fp64")
+        try:
+            import torch.distributed as tdist
+            if not tdist.is_initialized():
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                os.environ.setdefault("MASTER_PORT", "29577")
+                tdist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(f"cuda:{local_rank}"))
+                own_pg = True
+            b4 = contacts_block(model_path, 131072, local_rank, seed, ksteps, kwarm, 1, tdist, 1, False,
+                                "BASELINE.json configs[4], one GPU's share: the configs[2] model at 131072 envs with the per-control-"
+                                "period RCCL all-gather of obs/reward (one rank; the N = 1 point of the N > 1 runs)")
+        except Exception as ex:
+            b4 = {"error": repr(ex)}
+        if own_pg:
+            tdist.destroy_process_group()
+        if rank == 0:
+            out["contacts_65536"] = b2
+            out["contacts_131072"] = b4
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
