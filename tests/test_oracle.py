@@ -242,3 +242,75 @@ def test_cg_matches_newton(hand_model):
         err = np.abs(out[SOL_CG][0] - out[SOL_NEWTON][0]).max() / np.abs(out[SOL_NEWTON][0]).max()
         assert err < 1e-7, (contacts, err)
         assert out[SOL_CG][1] >= out[SOL_NEWTON][1]
+
+
+def test_contact_rows_and_dual_qp_third_opinion(hand_model):
+    """With contacts (self-collision + the ground plane): (a) the oracle's pyramid rows
+    J_n +- mu J_t are rebuilt from an independent NumPy point Jacobian (host_jac) of the two bodies at
+    the contact point and the contact frame; (b) the Newton solution equals the solution of the DUAL
+    problem  min_f  1/2 f^T (J M^-1 J^T + R) f + f^T (J a_smooth - aref)  over the row-wise bounds
+    (equality: free, frictionloss: |f| <= loss, limit / pyramid rows: f >= 0), solved by SciPy's
+    bounded L-BFGS from zero — a formulation that shares nothing with the oracle's primal Newton."""
+    from scipy.optimize import minimize
+    m = workload.with_ground_plane(hand_model, z=-0.05)
+    checked = 0
+    for seed in (1235, 77, 4242, 31):
+        q, v = workload.config2_state(m, 6, seed=seed)
+        c = workload.config2_ctrl(m, 6, seed=seed)
+        for e in range(6):
+            s = OracleSim(m)
+            s.qpos[:] = q[e]
+            s.qvel[:] = 0.2 * np.random.default_rng(seed + e).normal(size=m.nv)
+            s.ctrl[:] = c[e]
+            s.forward()
+            cons = s.contacts()
+            if not cons:
+                continue
+            typ, ids, J, D, aref, f = s.efc("type"), s.efc("id"), s.efc("J"), s.efc("D"), s.efc("aref"), s.efc("force")
+            fl = s.efc("frictionloss")
+            fk = host_fk(m, s.qpos)
+            # (a) contact rows from the independent Jacobian
+            rows = np.flatnonzero(typ == 6)
+            assert len(rows) == 4 * sum(1 for cc in cons if cc["dist"] < cc["includemargin"])
+            r = 0
+            for ci, cc in enumerate(cons):
+                if not cc["dist"] < cc["includemargin"]:
+                    continue
+                b1, b2 = int(m.geom_bodyid[cc["geom1"]]), int(m.geom_bodyid[cc["geom2"]])
+                j1, _ = host_jac(m, fk, b1, cc["pos"])
+                j2, _ = host_jac(m, fk, b2, cc["pos"])
+                fr = cc["frame"].reshape(3, 3)
+                Jc = fr @ (j2 - j1)
+                mu = max(m.geom_friction[cc["geom1"], 0], m.geom_friction[cc["geom2"], 0])
+                want = np.stack([Jc[0] + mu * Jc[1], Jc[0] - mu * Jc[1], Jc[0] + mu * Jc[2], Jc[0] - mu * Jc[2]])
+                got = J[rows[r:r + 4]]
+                assert (ids[rows[r:r + 4]] == ci).all()
+                assert np.abs(got - want).max() < 1e-12, (seed, e, ci)
+                # all four rows of a contact share D; the frame is orthonormal with x = contact normal
+                assert np.ptp(D[rows[r:r + 4]]) == 0 and np.abs(fr @ fr.T - np.eye(3)).max() < 1e-12
+                r += 4
+            # (b) dual QP
+            M = host_mass_matrix(m, fk)
+            assert np.abs(M - s.full_m()).max() < 1e-12 * np.abs(M).max()
+            Minv = np.linalg.inv(M)
+            A = J @ Minv @ J.T + np.diag(1.0 / D)
+            b = J @ s.qacc_smooth - aref
+            lo = np.where(typ == 0, -np.inf, np.where(typ == 1, -fl, 0.0))
+            hi = np.where(typ == 1, fl, np.inf)
+            sc = 1.0 / np.sqrt(np.diag(A))  # Jacobi scaling: the rows' regularisers span orders of magnitude
+            As, bs = A * sc[:, None] * sc[None, :], b * sc
+            res = minimize(lambda x: (0.5 * x @ As @ x + x @ bs, As @ x + bs), np.zeros(len(b)), jac=True, method="L-BFGS-B",
+                           bounds=list(zip(lo / sc, hi / sc)), options=dict(maxiter=20000, ftol=1e-16, gtol=1e-13, maxcor=50))
+            fd = res.x * sc
+            qacc_dual = s.qacc_smooth + Minv @ (J.T @ fd)
+            scale = max(1.0, np.abs(s.qacc).max())
+            assert np.abs(qacc_dual - s.qacc).max() / scale < 2e-5, (seed, e, np.abs(qacc_dual - s.qacc).max() / scale)
+            # the oracle's forces satisfy the dual KKT conditions: residual w = A f + b is >= 0 on rows at
+            # their lower bound, <= 0 at the upper bound, ~0 in between (the rows' own scale)
+            w = (A @ f + b) * sc
+            tol = 1e-6 * max(1.0, np.abs(bs).max())
+            at_lo, at_hi = f <= lo + 1e-12, f >= hi - 1e-12
+            assert (w[at_lo & ~at_hi] > -tol).all() and (w[at_hi & ~at_lo] < tol).all()
+            assert np.abs(w[~at_lo & ~at_hi]).max(initial=0.0) < tol
+            checked += 1
+    assert checked >= 12
