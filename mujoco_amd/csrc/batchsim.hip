@@ -370,7 +370,7 @@ extern "C" int bs_model_create(const bs_model_desc* desc, bs_model** out) {
              {&m->d.geom_rbound, (size_t)ng}, {&m->d.geom_margin, (size_t)ng}, {&m->d.geom_gap, (size_t)ng},
              {&m->d.geom_friction, (size_t)ng * 3}, {&m->d.geom_solref, (size_t)ng * 2},
              {&m->d.geom_solimp, (size_t)ng * 5}, {&m->d.geom_solmix, (size_t)ng},
-             {&m->d.hull_vert, (size_t)desc->nhullvert * 3},
+             {&m->d.hull_vert, (size_t)desc->nhullvert * 3}, {&m->d.geom_size, (size_t)(desc->geom_size ? ng * 3 : 0)},
              {&m->d.actuator_ctrlrange, (size_t)nu * 2}, {&m->d.actuator_forcerange, (size_t)nu * 2},
              {&m->d.actuator_gear, (size_t)nu}, {&m->d.actuator_gainprm, (size_t)nu * 3},
              {&m->d.actuator_biasprm, (size_t)nu * 3}, {&m->d.eq_data, (size_t)ne * 5},
@@ -588,6 +588,18 @@ static int model_image(bs_model* m, int device, const DeviceImage** out) {
     for (int k = 0; k < 3; k++) { obb[6 * g + k] = 0.5 * (lo[k] + hi[k]); obb[6 * g + 3 + k] = 0.5 * (hi[k] - lo[k]); }
   }
   PUT_CD(geom_obb, obb.data(), obb.size());
+  std::vector<double> gsize((size_t)(ng > 0 ? ng : 1) * 3, 0.0);
+  if (s.geom_size) memcpy(gsize.data(), s.geom_size, (size_t)ng * 3 * sizeof(double));
+  PUT_CD(geom_size, gsize.data(), gsize.size());
+  // sub-contacts per candidate pair (0: geom types no collision routine handles, e.g. height fields)
+  std::vector<int32_t> nsub((size_t)(s.npair > 0 ? s.npair : 1), 0);
+  cm.has_prim = 0;
+  for (int p = 0; p < s.npair; p++) {
+    const int t1 = s.geom_type[s.pair_geom1[p]], t2 = s.geom_type[s.pair_geom2[p]];
+    nsub[p] = pair_supported_types(t1, t2) ? pair_nsub_types(t1, t2) : 0;
+    if (nsub[p] && !((t1 == BS_GEOM_PLANE || t1 == BS_GEOM_MESH) && t2 == BS_GEOM_MESH)) cm.has_prim = 1;
+  }
+  PUT_CI(pair_nsub, nsub.data(), nsub.size());
 #undef PUT_CI
 #undef PUT_CD
   TpModel tp = m->tp;
@@ -710,9 +722,9 @@ static inline dim3 grid_tp(const bs_sim* s) { return dim3((unsigned)((s->n_envs 
 static void launch_narrow(bs_sim* s, const DevData& dd, hipStream_t st) {
   const dim3 g((unsigned)((dd.n_envs - dd.env0 + NB_ENVS - 1) / NB_ENVS));
   if (s->narrow_ws)
-    bs_launch_narrow_ws(g, st, s->cm, dd, s->cd);
+    bs_launch_narrow_ws(g, st, s->cm, dd, s->cd);  // mesh / plane pairs only (bs_sim_create falls back to blocks otherwise)
   else
-    bs_launch_narrow_flat(g, st, s->cm, dd, s->cd);
+    bs_launch_narrow_flat(g, st, s->cm, dd, s->cd, s->cm.has_prim);
 }
 // one forward pass (mode 1) or step (mode 0) with contacts through the tree-parallel kernels, for
 // the environments [dd.env0, dd.n_envs) on stream st
@@ -725,7 +737,7 @@ static void launch_tpc_pass(bs_sim* s, const DevData& dd, hipStream_t st, int mo
   } else {
     size_t nb = ((size_t)(dd.n_envs - dd.env0) * s->cm.maxcand + NL_THREADS - 1) / NL_THREADS;
     nb = nb < 1 ? 1 : nb > 16384 ? 16384 : nb;
-    bs_launch_narrow_list(dim3((unsigned)nb), st, s->cm, dd, s->cd);
+    bs_launch_narrow_list(dim3((unsigned)nb), st, s->cm, dd, s->cd, s->cm.has_prim);
   }
   const int ntri = s->dm.nbody * (s->dm.nbody + 1) / 2;
   const size_t lds = (size_t)(2 * ntri + 2 * TP_LPE * TPC_SLOT + 2 * TP_LPE * 3) * sizeof(double);
@@ -860,7 +872,16 @@ extern "C" int bs_sim_create(const bs_model* const* models, int n_models, const 
   s->contacts = contacts;
   s->cm = img->cm;
   s->cm.maxcon = (opt && opt->max_contacts_per_env > 0) ? opt->max_contacts_per_env : 32;
-  s->cm.maxcand = model->d.npair < 256 ? model->d.npair : 256;
+  {
+    // candidate slots: one per sub-contact of every pair (plane-capsule 2, plane-box 8, else 1), at most 256
+    // (the work list packs the slot into 8 bits)
+    long slots = 0;
+    for (int p = 0; p < model->d.npair; p++) {
+      const int t1 = model->d.geom_type[model->d.pair_geom1[p]], t2 = model->d.geom_type[model->d.pair_geom2[p]];
+      slots += pair_supported_types(t1, t2) ? pair_nsub_types(t1, t2) : 0;
+    }
+    s->cm.maxcand = slots < 1 ? 1 : (slots < 256 ? (int)slots : 256);
+  }
   // every solver with either integrator, with and without contacts (PGS with contacts: Euler)
   const bool serial = kv && strcmp(kv, "serial") == 0;
   const bool tp_solver = model->d.solver == 2 || model->d.solver == 1;
@@ -868,7 +889,7 @@ extern "C" int bs_sim_create(const bs_model* const* models, int n_models, const 
   s->use_tpc = contacts && tp_solver && model->tp_ok && s->cm.maxcon <= TP_LPE && !serial;
   {
     const char* nk = getenv("BS_NARROW");
-    s->narrow_ws = nk && strcmp(nk, "ws") == 0;
+    s->narrow_ws = nk && strcmp(nk, "ws") == 0 && !s->cm.has_prim;  // the work-stealing variant knows hulls and planes only
     s->narrow_blocks = nk && strcmp(nk, "blocks") == 0;
   }
   if (kv && strcmp(kv, "tp") == 0 && !model->tp_ok) {

@@ -5,6 +5,7 @@
 // narrowphase over the flattened (environment, candidate slot) items of NB_ENVS environments:
 // an exclusive scan of the candidate counts in LDS, then every lane takes items round-robin, so
 // no lane idles on environments with few candidates and no wavefront is launched for empty slots
+template <bool PRIM>
 __global__ __launch_bounds__(NB_THREADS) void k_c_narrow_flat(ColModel cm, DevData d, ColData c) {
   __shared__ int pre[NB_ENVS + 1];
   __shared__ MprState mpr[NB_THREADS];  // MPR state of every lane (see mpr_penetration)
@@ -30,7 +31,7 @@ __global__ __launch_bounds__(NB_THREADS) void k_c_narrow_flat(ColModel cm, DevDa
       if (pre[mid] <= item) lo = mid;
       else hi = mid;
     }
-    col_narrowphase(cm, d, c, e0 + lo, item - pre[lo], acc, mpr[tid]);
+    col_narrowphase<PRIM>(cm, d, c, e0 + lo, item - pre[lo], acc, mpr[tid]);
   }
   if (c.stat) {  // work counters: wavefront reduction, then one atomic each
     for (int off = 32; off > 0; off >>= 1) {
@@ -74,6 +75,7 @@ __global__ __launch_bounds__(NW_THREADS) void k_c_narrow_ws(ColModel cm, DevData
 }
 // narrowphase over the work list k_tp_col wrote: one lane per item whatever environment it belongs
 // to, so every wavefront but the last is full
+template <bool PRIM>
 __global__ __launch_bounds__(NL_THREADS) void k_c_narrow_list(ColModel cm, DevData d, ColData c) {
   __shared__ unsigned pre[BS_NSUB + 1];
   __shared__ MprState mpr[NL_THREADS];
@@ -100,7 +102,7 @@ __global__ __launch_bounds__(NL_THREADS) void k_c_narrow_list(ColModel cm, DevDa
       else hi = mid;
     }
     const int it = items[lo * subcap + (i - pre[lo])];
-    col_narrowphase(cm, d, c, d.env0 + (it >> 8), it & 255, acc, mpr[tid]);
+    col_narrowphase<PRIM>(cm, d, c, d.env0 + (it >> 8), it & 255, acc, mpr[tid]);
   }
   if (c.stat) {
     for (int off = 32; off > 0; off >>= 1) {
@@ -114,14 +116,18 @@ __global__ __launch_bounds__(NL_THREADS) void k_c_narrow_list(ColModel cm, DevDa
   }
 }
 
-void bs_launch_narrow_flat(dim3 g, hipStream_t st, const ColModel& cm, const DevData& d, const ColData& c) {
-  hipLaunchKernelGGL(k_c_narrow_flat, g, dim3(NB_THREADS), 0, st, cm, d, c);
+// prim: the model has pairs with primitive geoms (the PRIM instantiation carries their closed forms and
+// support functions; hull / plane-only models run the lean one)
+void bs_launch_narrow_flat(dim3 g, hipStream_t st, const ColModel& cm, const DevData& d, const ColData& c, int prim) {
+  if (prim) hipLaunchKernelGGL(k_c_narrow_flat<true>, g, dim3(NB_THREADS), 0, st, cm, d, c);
+  else hipLaunchKernelGGL(k_c_narrow_flat<false>, g, dim3(NB_THREADS), 0, st, cm, d, c);
 }
 void bs_launch_narrow_ws(dim3 g, hipStream_t st, const ColModel& cm, const DevData& d, const ColData& c) {
   hipLaunchKernelGGL(k_c_narrow_ws, g, dim3(NW_THREADS), 0, st, cm, d, c);
 }
-void bs_launch_narrow_list(dim3 g, hipStream_t st, const ColModel& cm, const DevData& d, const ColData& c) {
-  hipLaunchKernelGGL(k_c_narrow_list, g, dim3(NL_THREADS), 0, st, cm, d, c);
+void bs_launch_narrow_list(dim3 g, hipStream_t st, const ColModel& cm, const DevData& d, const ColData& c, int prim) {
+  if (prim) hipLaunchKernelGGL(k_c_narrow_list<true>, g, dim3(NL_THREADS), 0, st, cm, d, c);
+  else hipLaunchKernelGGL(k_c_narrow_list<false>, g, dim3(NL_THREADS), 0, st, cm, d, c);
 }
 #ifdef NP_PROFILE
 void bs_np_profile_dump() {

@@ -34,9 +34,9 @@ void bs_launch_c_dyn(dim3 g, size_t lds, hipStream_t st, const DevModel& m, cons
 hipError_t bs_c_dyn_set_lds(int bytes);  // hipFuncSetAttribute(MaxDynamicSharedMemorySize) on k_c_dyn
 
 // ---- narrowphase, k_narrow.hip
-void bs_launch_narrow_flat(dim3 g, hipStream_t st, const ColModel& cm, const DevData& d, const ColData& c);
+void bs_launch_narrow_flat(dim3 g, hipStream_t st, const ColModel& cm, const DevData& d, const ColData& c, int prim);
 void bs_launch_narrow_ws(dim3 g, hipStream_t st, const ColModel& cm, const DevData& d, const ColData& c);
-void bs_launch_narrow_list(dim3 g, hipStream_t st, const ColModel& cm, const DevData& d, const ColData& c);
+void bs_launch_narrow_list(dim3 g, hipStream_t st, const ColModel& cm, const DevData& d, const ColData& c, int prim);
 #ifdef NP_PROFILE
 void bs_np_profile_dump();
 #endif

@@ -15,7 +15,19 @@
 #include "physics_dev.h"
 
 #define BS_CCD_EPS 2.220446049250313e-16
-enum { BS_GEOM_PLANE = 0, BS_GEOM_MESH = 7 };
+enum { BS_GEOM_PLANE = 0, BS_GEOM_HFIELD = 1, BS_GEOM_SPHERE = 2, BS_GEOM_CAPSULE = 3, BS_GEOM_ELLIPSOID = 4,
+       BS_GEOM_CYLINDER = 5, BS_GEOM_BOX = 6, BS_GEOM_MESH = 7 };
+// a candidate slot names one potential contact: pair id in the low 24 bits, sub-contact in the high 8
+// (plane-capsule: 2 cap centres, plane-box: 8 corners, every other pair: 1)
+#define BS_PAIR_MASK 0xFFFFFF
+__host__ __device__ inline int pair_nsub_types(int t1, int t2) {
+  if (t1 == BS_GEOM_PLANE && t2 == BS_GEOM_CAPSULE) return 2;
+  if (t1 == BS_GEOM_PLANE && t2 == BS_GEOM_BOX) return 8;
+  return 1;
+}
+__host__ __device__ inline bool pair_supported_types(int t1, int t2) {  // t1 <= t2 (model.py::_build_pairs)
+  return t1 != BS_GEOM_HFIELD && t2 != BS_GEOM_HFIELD && t2 != BS_GEOM_PLANE;
+}
 
 struct ColModel {
   int npair, ngeom, maxcand, maxcon, mpr_iterations;
@@ -34,6 +46,9 @@ struct ColModel {
   const double4 *hull_vert4; // [nhullvert]
   const int2 *hull_range;    // [nhullvert]
   const double *geom_obb; // [ngeom][6] box around the hull in the geom frame: centre, half extents (< 0: none)
+  const double *geom_size; // [ngeom][3] mjModel.geom_size (primitives)
+  const int *pair_nsub;    // [npair] sub-contacts a pair can produce (0: pair of unsupported geom types)
+  int has_prim;            // some pair involves a primitive geom: the narrowphase kernels' PRIM instantiation runs
 };
 
 // cube-map direction bins: 6 faces x BS_SG x BS_SG
@@ -113,6 +128,8 @@ __device__ __forceinline__ int rec_deg(double w) { return (__double2loint(w) >> 
 __device__ __forceinline__ int rec_k0(double w) { return __double2hiint(w); }
 
 struct CObj {
+  int type;        // BS_GEOM_* (PRIM instantiations only)
+  V3 size;         // geom_size (primitives)
   // vert4: this mesh's vertices, nbr4: global adjacency records, start4: this mesh's start table;
   // every record is {x, y, z, id | degree << 20 | first adjacency entry << 32}, so a climb step is
   // one dependent load (the neighbours of the vertex just chosen), not two
@@ -432,6 +449,82 @@ __device__ inline bool mpr_penetration(CObj& a, CObj& b, double tol, int maxit, 
   }
 }
 
+// ---- primitive geoms (north_star "plus plane/primitive pairs"; same closed forms and support
+// functions as oracle/oracle_collide.c).  Ties (a direction component of exactly 0) take the positive side.
+__device__ inline V3 geom_support_any(CObj& o, const V3& dir) {
+  if (o.type == BS_GEOM_MESH) return hull_support(o, dir);
+  const M3& R = o.R;
+  const V3 d = {R.a[0] * dir.x + R.a[3] * dir.y + R.a[6] * dir.z, R.a[1] * dir.x + R.a[4] * dir.y + R.a[7] * dir.z,
+                R.a[2] * dir.x + R.a[5] * dir.y + R.a[8] * dir.z};
+  V3 v = {0, 0, 0};
+  double infl = o.margin;
+  switch (o.type) {
+    case BS_GEOM_SPHERE: infl += o.size.x; break;
+    case BS_GEOM_CAPSULE: v.z = d.z >= 0 ? o.size.y : -o.size.y; infl += o.size.x; break;
+    case BS_GEOM_CYLINDER: {
+      const double l = sqrt(d.x * d.x + d.y * d.y);
+      if (l > 0) { v.x = o.size.x * d.x / l; v.y = o.size.x * d.y / l; }
+      v.z = d.z >= 0 ? o.size.y : -o.size.y;
+      break;
+    }
+    case BS_GEOM_BOX:
+      v = {d.x >= 0 ? o.size.x : -o.size.x, d.y >= 0 ? o.size.y : -o.size.y, d.z >= 0 ? o.size.z : -o.size.z};
+      break;
+    case BS_GEOM_ELLIPSOID: {
+      const double s0 = o.size.x * d.x, s1 = o.size.y * d.y, s2 = o.size.z * d.z, l = sqrt(s0 * s0 + s1 * s1 + s2 * s2);
+      if (l > 0) v = {o.size.x * s0 / l, o.size.y * s1 / l, o.size.z * s2 / l};
+      break;
+    }
+    default: break;
+  }
+  const V3 w = mrot(R, v);
+  return {o.xpos.x + w.x + infl * dir.x, o.xpos.y + w.y + infl * dir.y, o.xpos.z + w.z + infl * dir.z};
+}
+// plane (point pp, normal n) against a point c of radius r: plane-capsule caps (r = radius), plane-box corners (r = 0)
+__device__ inline bool plane_point(const V3& pp, const V3& n, const V3& c, double r, double margin, double& dist, V3& pos) {
+  const double ds = dot(sub(c, pp), n) - r;
+  if (ds > margin) return false;
+  dist = ds;
+  const double k = r + 0.5 * ds;
+  pos = {c.x - k * n.x, c.y - k * n.y, c.z - k * n.z};
+  return true;
+}
+__device__ inline bool sphere_sphere(const V3& c1, double r1, const V3& c2, double r2, double margin, double& dist, V3& pos,
+                                     V3& nrm) {
+  const V3 df = sub(c2, c1);
+  const double len = sqrt(dot(df, df));
+  if (len - r1 - r2 > margin) return false;
+  if (len < 1e-15) nrm = {1, 0, 0};
+  else nrm = {df.x / len, df.y / len, df.z / len};
+  dist = len - r1 - r2;
+  const double k = r1 + 0.5 * dist;
+  pos = {c1.x + k * nrm.x, c1.y + k * nrm.y, c1.z + k * nrm.z};
+  return true;
+}
+__device__ inline V3 seg_closest_point(const V3& c, const V3& axis, double h, const V3& p) {
+  double t = dot(sub(p, c), axis);
+  t = t > h ? h : (t < -h ? -h : t);
+  return {c.x + t * axis.x, c.y + t * axis.y, c.z + t * axis.z};
+}
+__device__ inline void seg_seg_closest(const V3& c1, const V3& a1, double h1, const V3& c2, const V3& a2, double h2, V3& p1,
+                                       V3& p2) {
+  const V3 w = sub(c1, c2);
+  const double b = dot(a1, a2), d1 = dot(a1, w), d2 = dot(a2, w), den = 1 - b * b;
+  double t1, t2;
+  if (den > 1e-12) {
+    t1 = (b * d2 - d1) / den;
+    t1 = t1 > h1 ? h1 : (t1 < -h1 ? -h1 : t1);
+  } else t1 = 0;  // parallel axes: start from the middle of segment 1
+  t2 = b * t1 + d2;
+  if (t2 > h2 || t2 < -h2) {
+    t2 = t2 > h2 ? h2 : -h2;
+    t1 = b * t2 - d1;
+    t1 = t1 > h1 ? h1 : (t1 < -h1 ? -h1 : t1);
+  }
+  p1 = {c1.x + t1 * a1.x, c1.y + t1 * a1.y, c1.z + t1 * a1.z};
+  p2 = {c2.x + t2 * a2.x, c2.y + t2 * a2.y, c2.z + t2 * a2.z};
+}
+
 // ---------------------------------------------------------------- kernels' bodies
 // geom frames for one environment lane (same arithmetic as k_frames, geoms only)
 __device__ inline void col_geom_frames(const DevModel& m, const DevData& d, const ColData& c, long e) {
@@ -518,13 +611,16 @@ __device__ inline void col_broadphase(const ColModel& cm, const DevData& d, cons
         const V3 n = {AT(c.geom_xmat, 9 * g1 + 2), AT(c.geom_xmat, 9 * g1 + 5), AT(c.geom_xmat, 9 * g1 + 8)};
         keep = !(dot(sub(x2, x1), n) > margin + r2);
       }
-      const int t1 = cm.geom_type[g1], t2 = cm.geom_type[g2];
-      if (!((t1 == BS_GEOM_PLANE || t1 == BS_GEOM_MESH) && t2 == BS_GEOM_MESH)) keep = false;
     }
-    const unsigned long long mask = __ballot(keep);
-    const int pos = count + __popcll(mask & ((1ull << lane) - 1ull));
-    if (keep && pos < cm.maxcand) AT(c.cand_pair, pos) = p;
-    count += __popcll(mask);
+    // a pair reserves pair_nsub consecutive slots (0 for geom types no routine handles): ordered
+    // compaction with a prefix sum of the counts (1, 2 or 8) from three ballots
+    const int cnt = keep ? cm.pair_nsub[p] : 0;
+    const unsigned long long lower = (1ull << lane) - 1ull;
+    const unsigned long long m1 = __ballot(cnt & 1), m2 = __ballot(cnt & 2), m8 = __ballot(cnt & 8);
+    const int pos = count + __popcll(m1 & lower) + 2 * __popcll(m2 & lower) + 8 * __popcll(m8 & lower);
+    for (int q = 0; q < cnt; q++)
+      if (pos + q < cm.maxcand) AT(c.cand_pair, pos + q) = p | (q << 24);
+    count += __popcll(m1) + 2 * __popcll(m2) + 8 * __popcll(m8);
   }
   if (lane == 0) {
     if (count > cm.maxcand) { count = cm.maxcand; AT(d.warning, 0) |= 8; }
@@ -535,30 +631,73 @@ __device__ inline void col_broadphase(const ColModel& cm, const DevData& d, cons
 // A6: one lane per (environment, candidate slot)
 // `acc` (optional): per-lane work counters {pairs, MPR support iterations}; the kernel reduces them
 // over the wavefront before touching ColData::stat (one atomic per wavefront, not per pair)
+template <bool PRIM = false>
 __device__ inline void col_narrowphase(const ColModel& cm, const DevData& d, const ColData& c, long e, int slot,
                                        unsigned* acc, MprState& M) {
   const long E = d.E;
   if (slot >= AT(c.ncand, 0)) return;
-  const int p = AT(c.cand_pair, slot);
+  const int ps = AT(c.cand_pair, slot);
+  const int p = ps & BS_PAIR_MASK;
   const int g1 = cm.pair_geom1[p], g2 = cm.pair_geom2[p];
   const double margin = fmax(cm.geom_margin[g1], cm.geom_margin[g2]);
-  CObj b;
-  {
-    const int mesh = cm.geom_dataid[g2];
-    b.vert4 = cm.hull_vert4 + cm.mesh_vertadr[mesh];
-    b.nbr4 = cm.hull_nbr4; b.cache = 0;
-    b.start4 = cm.hull_start4 + (size_t)mesh * BS_NSTART;
-    b.xpos = {AT(c.geom_xpos, 3 * g2), AT(c.geom_xpos, 3 * g2 + 1), AT(c.geom_xpos, 3 * g2 + 2)};
-    for (int k = 0; k < 9; k++) b.R.a[k] = AT(c.geom_xmat, 9 * g2 + k);
-  }
   bool hit = false;
   double dist = 0;
   V3 pos = {0, 0, 0}, nrm = {0, 0, 0};
-  if (cm.geom_type[g1] == BS_GEOM_PLANE) {
+  auto load_obj = [&](CObj& o, int g) {
+    o.type = BS_GEOM_MESH; o.size = {0, 0, 0};
+    if constexpr (PRIM) { o.type = cm.geom_type[g]; o.size = ld3(cm.geom_size + 3 * g); }
+    const int mesh = (!PRIM || o.type == BS_GEOM_MESH) ? cm.geom_dataid[g] : 0;
+    o.vert4 = cm.hull_vert4 + cm.mesh_vertadr[mesh];
+    o.nbr4 = cm.hull_nbr4; o.cache = 0;
+    o.start4 = cm.hull_start4 + (size_t)mesh * BS_NSTART;
+    o.xpos = {AT(c.geom_xpos, 3 * g), AT(c.geom_xpos, 3 * g + 1), AT(c.geom_xpos, 3 * g + 2)};
+    for (int k = 0; k < 9; k++) o.R.a[k] = AT(c.geom_xmat, 9 * g + k);
+    o.margin = 0;
+  };
+  CObj b;
+  load_obj(b, g2);
+  const int t1 = cm.geom_type[g1];
+  bool done = false;
+  if constexpr (PRIM) {
+    const int t2 = b.type, sub = ps >> 24;
+    if (t1 == BS_GEOM_PLANE && (t2 == BS_GEOM_CAPSULE || t2 == BS_GEOM_BOX)) {
+      const V3 n = {AT(c.geom_xmat, 9 * g1 + 2), AT(c.geom_xmat, 9 * g1 + 5), AT(c.geom_xmat, 9 * g1 + 8)};
+      const V3 pp = {AT(c.geom_xpos, 3 * g1), AT(c.geom_xpos, 3 * g1 + 1), AT(c.geom_xpos, 3 * g1 + 2)};
+      V3 v;
+      double r = 0;
+      if (t2 == BS_GEOM_CAPSULE) { v = {0, 0, sub == 0 ? b.size.y : -b.size.y}; r = b.size.x; }  // cap centre +axis, then -axis
+      else v = {sub & 1 ? -b.size.x : b.size.x, sub & 2 ? -b.size.y : b.size.y, sub & 4 ? -b.size.z : b.size.z};
+      const V3 w = mrot(b.R, v);
+      hit = plane_point(pp, n, V3{b.xpos.x + w.x, b.xpos.y + w.y, b.xpos.z + w.z}, r, margin, dist, pos);
+      nrm = n;
+      done = true;
+    } else if (t1 == BS_GEOM_SPHERE || (t1 == BS_GEOM_CAPSULE && t2 == BS_GEOM_CAPSULE)) {
+      const V3 x1 = {AT(c.geom_xpos, 3 * g1), AT(c.geom_xpos, 3 * g1 + 1), AT(c.geom_xpos, 3 * g1 + 2)};
+      const V3 s1 = ld3(cm.geom_size + 3 * g1);
+      const V3 a2 = {b.R.a[2], b.R.a[5], b.R.a[8]};
+      if (t1 == BS_GEOM_SPHERE && t2 == BS_GEOM_SPHERE) {
+        hit = sphere_sphere(x1, s1.x, b.xpos, b.size.x, margin, dist, pos, nrm);
+        done = true;
+      } else if (t1 == BS_GEOM_SPHERE && t2 == BS_GEOM_CAPSULE) {
+        hit = sphere_sphere(x1, s1.x, seg_closest_point(b.xpos, a2, b.size.y, x1), b.size.x, margin, dist, pos, nrm);
+        done = true;
+      } else if (t1 == BS_GEOM_CAPSULE) {
+        const V3 a1 = {AT(c.geom_xmat, 9 * g1 + 2), AT(c.geom_xmat, 9 * g1 + 5), AT(c.geom_xmat, 9 * g1 + 8)};
+        V3 p1, p2;
+        seg_seg_closest(x1, a1, s1.y, b.xpos, a2, b.size.y, p1, p2);
+        hit = sphere_sphere(p1, s1.x, p2, b.size.x, margin, dist, pos, nrm);
+        done = true;
+      }
+    }
+  }
+  if (done) {
+  } else if (t1 == BS_GEOM_PLANE) {
     b.margin = 0;
     const V3 n = {AT(c.geom_xmat, 9 * g1 + 2), AT(c.geom_xmat, 9 * g1 + 5), AT(c.geom_xmat, 9 * g1 + 8)};
     const V3 pp = {AT(c.geom_xpos, 3 * g1), AT(c.geom_xpos, 3 * g1 + 1), AT(c.geom_xpos, 3 * g1 + 2)};
-    const V3 v = hull_support(b, neg(n));
+    V3 v;
+    if constexpr (PRIM) v = geom_support_any(b, neg(n));
+    else v = hull_support(b, neg(n));
     const double ds = dot(sub(v, pp), n);
     if (!(ds > margin)) {
       hit = true; dist = ds; nrm = n;
@@ -566,18 +705,26 @@ __device__ inline void col_narrowphase(const ColModel& cm, const DevData& d, con
     }
   } else {
     CObj a;
-    const int mesh = cm.geom_dataid[g1];
-    a.vert4 = cm.hull_vert4 + cm.mesh_vertadr[mesh];
-    a.nbr4 = cm.hull_nbr4; a.cache = 0;
-    a.start4 = cm.hull_start4 + (size_t)mesh * BS_NSTART;
-    a.xpos = {AT(c.geom_xpos, 3 * g1), AT(c.geom_xpos, 3 * g1 + 1), AT(c.geom_xpos, 3 * g1 + 2)};
-    for (int k = 0; k < 9; k++) a.R.a[k] = AT(c.geom_xmat, 9 * g1 + k);
+    load_obj(a, g1);
     a.margin = 0.5 * margin; b.margin = 0.5 * margin;
     double depth;
     int iters = 0;
-    if (mpr_penetration(a, b, cm.mpr_tolerance, cm.mpr_iterations, depth, nrm, pos, iters, M)) {
-      if (!(nrm.x == 0 && nrm.y == 0 && nrm.z == 0)) { hit = true; dist = margin - depth; }
+    bool pen;
+    if (PRIM && !(a.type == BS_GEOM_MESH && b.type == BS_GEOM_MESH)) {
+      // the same portal refinement around the primitives' support functions
+      mpr_begin(M, a.xpos, b.xpos);
+      for (;;) {
+        Spt s;
+        s.v1 = geom_support_any(a, M.d);
+        s.v2 = geom_support_any(b, neg(M.d));
+        s.v = sub(s.v1, s.v2);
+        const int r = mpr_step(M, s, a.xpos, b.xpos, cm.mpr_tolerance, cm.mpr_iterations, depth, nrm, pos, iters);
+        if (r) { pen = r == 1; break; }
+      }
+    } else {
+      pen = mpr_penetration(a, b, cm.mpr_tolerance, cm.mpr_iterations, depth, nrm, pos, iters, M);
     }
+    if (pen && !(nrm.x == 0 && nrm.y == 0 && nrm.z == 0)) { hit = true; dist = margin - depth; }
     if (acc) { acc[0] += 1; acc[1] += (unsigned)iters; }
     else if (c.stat) { atomicAdd(c.stat, 1ull); atomicAdd(c.stat + 1, (unsigned long long)iters); }
   }
@@ -640,7 +787,7 @@ __device__ inline void col_narrow_ws(const ColModel& cm, const DevData& d, const
             else hi = mid;
           }
           e = e0 + lo; slot = item - pre[lo];
-          const int p = AT(c.cand_pair, slot);
+          const int p = AT(c.cand_pair, slot) & BS_PAIR_MASK;
           const int g1 = cm.pair_geom1[p], g2 = cm.pair_geom2[p];
           margin = fmax(cm.geom_margin[g1], cm.geom_margin[g2]);
           bmesh = cm.geom_dataid[g2];
@@ -744,7 +891,7 @@ __device__ inline void col_assemble(const ColModel& cm, const DevData& d, const 
   for (int s = 0; s < nc; s++) {
     if (!AT(c.cand_hit, s)) continue;
     if (n >= cm.maxcon) { AT(d.warning, 0) |= 8; break; }
-    AT(c.con_pair, n) = AT(c.cand_pair, s);
+    AT(c.con_pair, n) = AT(c.cand_pair, s) & BS_PAIR_MASK;
     AT(c.con_dist, n) = AT(c.cand_dist, s);
     for (int k = 0; k < 3; k++) AT(c.con_pos, 3 * n + k) = AT(c.cand_pos, 3 * s + k);
     V3 x = normalized(V3{AT(c.cand_nrm, 3 * s), AT(c.cand_nrm, 3 * s + 1), AT(c.cand_nrm, 3 * s + 2)});

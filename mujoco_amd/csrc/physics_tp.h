@@ -790,8 +790,8 @@ __device__ __forceinline__ void tp_collide_prep(const DevModel& m, const TpModel
     bool keep = false;
     if (p < cm.npair) {
       const int g1 = cm.pair_geom1[p], g2 = cm.pair_geom2[p];
-      const int t1 = cm.geom_type[g1], t2 = cm.geom_type[g2];
-      if ((t1 == BS_GEOM_PLANE || t1 == BS_GEOM_MESH) && t2 == BS_GEOM_MESH) {
+      const int t1 = cm.geom_type[g1];
+      {
         const double margin = fmax(cm.geom_margin[g1], cm.geom_margin[g2]);
         const double r1 = cm.geom_rbound[g1], r2 = cm.geom_rbound[g2];
         const tp_lds_d s1 = G + g1 * TPG_SLOT, s2 = G + g2 * TPG_SLOT;
@@ -812,10 +812,17 @@ __device__ __forceinline__ void tp_collide_prep(const DevModel& m, const TpModel
         }
       }
     }
-    const unsigned bits = (unsigned)(__ballot(keep) >> base);
-    const int at = count + __popc(bits & ((1u << l) - 1u));
-    if (keep && at < cm.maxcand && env_ok) AT(cd.cand_pair, at) = p;
-    count += __popc(bits);
+    // a pair reserves pair_nsub consecutive slots (1, 2 or 8; 0 for geom types no routine handles):
+    // ordered compaction with a prefix sum of the counts from three ballots
+    const int cnt = keep ? cm.pair_nsub[p] : 0;
+    const unsigned lower = (1u << l) - 1u;
+    const unsigned m1 = (unsigned)(__ballot(cnt & 1) >> base), m2 = (unsigned)(__ballot(cnt & 2) >> base),
+                   m8 = (unsigned)(__ballot(cnt & 8) >> base);
+    const int at = count + __popc(m1 & lower) + 2 * __popc(m2 & lower) + 8 * __popc(m8 & lower);
+    if (env_ok)
+      for (int q = 0; q < cnt; q++)
+        if (at + q < cm.maxcand) AT(cd.cand_pair, at + q) = p | (q << 24);
+    count += __popc(m1) + 2 * __popc(m2) + 8 * __popc(m8);
   }
   if (l == 0 && env_ok) {
     if (count > cm.maxcand) AT(d.warning, 0) |= 8;
@@ -1198,7 +1205,7 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
           const unsigned bits = (unsigned)(__ballot(hit) >> base);
           const int n = count + __popc(bits & ((1u << l) - 1u));
           if (hit && n < cm.maxcon) {
-            const int pr = AT(cd.cand_pair, sidx);
+            const int pr = AT(cd.cand_pair, sidx) & BS_PAIR_MASK;
             const double dist = AT(cd.cand_dist, sidx);
             const V3 p = {AT(cd.cand_pos, 3 * sidx), AT(cd.cand_pos, 3 * sidx + 1), AT(cd.cand_pos, 3 * sidx + 2)};
             const V3 x = normalized(V3{AT(cd.cand_nrm, 3 * sidx), AT(cd.cand_nrm, 3 * sidx + 1), AT(cd.cand_nrm, 3 * sidx + 2)});

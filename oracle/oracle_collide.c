@@ -11,6 +11,13 @@
  *     support by steepest-ascent hill climbing over the hull's vertex graph; at most ONE contact
  *     per pair; dist = margin - depth, position = MPR's barycentric estimate;
  *   - plane-mesh (the build's own ground plane): deepest hull vertex;
+ *   - primitive geoms (north_star "plus plane/primitive pairs"; the dialect's geom default is mesh,
+ *     src/Mujoco_XML.py:70, primitives only appear when a user edits it): closed forms for
+ *     plane-sphere / plane-capsule (2 contacts) / plane-box (one per corner below the margin),
+ *     sphere-sphere, sphere-capsule, capsule-capsule (closest points of the segments, ONE contact);
+ *     every other convex pair (box, cylinder, ellipsoid, mesh in any combination, sphere-box,
+ *     capsule-box) goes through the same MPR with the primitives' support functions — MuJoCo's
+ *     native box-box / capsule-box routines return more contacts per pair [EXT], this returns one;
  *   - contact parameters: friction/condim = max over the geoms, solref/solimp mixed by solmix,
  *     margin/gap = max; tangent frame completed as mju_makeFrame does.
  */
@@ -20,7 +27,8 @@
 #include <math.h>
 #include <string.h>
 
-enum { GEOM_PLANE = 0, GEOM_MESH = 7 };
+enum { GEOM_PLANE = 0, GEOM_HFIELD = 1, GEOM_SPHERE = 2, GEOM_CAPSULE = 3, GEOM_ELLIPSOID = 4, GEOM_CYLINDER = 5,
+       GEOM_BOX = 6, GEOM_MESH = 7 };
 enum { DSBL_CONTACT = 1 << 4 };
 
 #define CCD_EPS DBL_EPSILON
@@ -46,6 +54,8 @@ static int vec_eq(const double *a, const double *b) { return is_eq(a[0], b[0]) &
 
 /* one convex object: a mesh geom's hull in world pose, inflated by `margin` */
 typedef struct {
+  int type;                     /* GEOM_* */
+  const double *size;           /* geom_size (primitives) */
   const double *vert;           /* hull vertices of the mesh (local) */
   const int32_t *adj_start, *adj; /* CSR adjacency: adj_start is absolute per global vertex */
   int nvert, vertadr;
@@ -78,10 +88,41 @@ static void hull_support(cobj *o, const double *dir, double *res) {
     res[r] = o->xpos[r] + R[3 * r] * v[0] + R[3 * r + 1] * v[1] + R[3 * r + 2] * v[2] + o->margin * dir[r];
 }
 
+/* support of any convex geom (inflated by o->margin) in world direction dir (unit length).  Ties
+ * (a direction component of exactly 0) take the positive side, on the device as well. */
+static void geom_support(cobj *o, const double *dir, double *res) {
+  if (o->type == GEOM_MESH) { hull_support(o, dir, res); return; }
+  const double *R = o->xmat, *sz = o->size;
+  double d[3] = {R[0] * dir[0] + R[3] * dir[1] + R[6] * dir[2], R[1] * dir[0] + R[4] * dir[1] + R[7] * dir[2],
+                 R[2] * dir[0] + R[5] * dir[1] + R[8] * dir[2]};
+  double v[3] = {0, 0, 0}, infl = o->margin;
+  switch (o->type) {
+    case GEOM_SPHERE: infl += sz[0]; break;
+    case GEOM_CAPSULE: v[2] = d[2] >= 0 ? sz[1] : -sz[1]; infl += sz[0]; break;
+    case GEOM_CYLINDER: {
+      double l = sqrt(d[0] * d[0] + d[1] * d[1]);
+      if (l > 0) { v[0] = sz[0] * d[0] / l; v[1] = sz[0] * d[1] / l; }
+      v[2] = d[2] >= 0 ? sz[1] : -sz[1];
+      break;
+    }
+    case GEOM_BOX:
+      for (int k = 0; k < 3; k++) v[k] = d[k] >= 0 ? sz[k] : -sz[k];
+      break;
+    case GEOM_ELLIPSOID: {
+      double s0 = sz[0] * d[0], s1 = sz[1] * d[1], s2 = sz[2] * d[2], l = sqrt(s0 * s0 + s1 * s1 + s2 * s2);
+      if (l > 0) { v[0] = sz[0] * s0 / l; v[1] = sz[1] * s1 / l; v[2] = sz[2] * s2 / l; }
+      break;
+    }
+    default: break;
+  }
+  for (int r = 0; r < 3; r++)
+    res[r] = o->xpos[r] + R[3 * r] * v[0] + R[3 * r + 1] * v[1] + R[3 * r + 2] * v[2] + infl * dir[r];
+}
+
 static void md_support(cobj *a, cobj *b, const double *dir, spt *s) {
   double nd[3] = {-dir[0], -dir[1], -dir[2]};
-  hull_support(a, dir, s->v1);
-  hull_support(b, nd, s->v2);
+  geom_support(a, dir, s->v1);
+  geom_support(b, nd, s->v2);
   sub3(s->v, s->v1, s->v2);
 }
 
@@ -278,12 +319,17 @@ static int mpr_penetration(cobj *a, cobj *b, double tol, int maxit, double *dept
 }
 
 static void make_cobj(const orc_model *m, const orc_data *d, int g, double margin, cobj *o) {
-  int mesh = m->geom_dataid[g];
-  o->vertadr = m->mesh_vertadr[mesh];
-  o->nvert = m->mesh_vertnum[mesh];
-  o->vert = m->hull_vert + 3 * (size_t)o->vertadr;
-  o->adj_start = m->hull_adj_start;
-  o->adj = m->hull_adj;
+  memset(o, 0, sizeof *o);
+  o->type = m->geom_type[g];
+  o->size = m->geom_size + 3 * g;
+  if (o->type == GEOM_MESH) {
+    int mesh = m->geom_dataid[g];
+    o->vertadr = m->mesh_vertadr[mesh];
+    o->nvert = m->mesh_vertnum[mesh];
+    o->vert = m->hull_vert + 3 * (size_t)o->vertadr;
+    o->adj_start = m->hull_adj_start;
+    o->adj = m->hull_adj;
+  }
   o->xpos = d->geom_xpos + 3 * g;
   o->xmat = d->geom_xmat + 9 * g;
   o->margin = margin;
@@ -316,14 +362,15 @@ static int convex_pair(const orc_model *m, const orc_data *d, int g1, int g2, do
   memcpy(normal, dir, 24);
   return 1;
 }
-/* plane (g1) - mesh (g2): the deepest hull vertex, contact at the midpoint */
+/* plane (g1) - convex (g2): the deepest point of the geom (its support along -normal), contact at
+ * the midpoint.  For a sphere this is mjc_PlaneSphere's closed form. */
 static int plane_pair(const orc_model *m, const orc_data *d, int g1, int g2, double margin, double *dist,
                       double *pos, double *normal) {
   cobj b;
   make_cobj(m, d, g2, 0.0, &b);
   const double *pm = d->geom_xmat + 9 * g1, *pp = d->geom_xpos + 3 * g1;
   double n[3] = {pm[2], pm[5], pm[8]}, nd[3] = {-pm[2], -pm[5], -pm[8]}, v[3], df[3];
-  hull_support(&b, nd, v);
+  geom_support(&b, nd, v);
   sub3(df, v, pp);
   double ds = dot3(df, n);
   if (ds > margin) return 0;
@@ -332,25 +379,117 @@ static int plane_pair(const orc_model *m, const orc_data *d, int g1, int g2, dou
   memcpy(normal, n, 24);
   return 1;
 }
+/* plane (g1) - point of g2 with radius r: the shared closed form of plane-capsule (cap centres,
+ * r = capsule radius) and plane-box (corners, r = 0) */
+static int plane_point(const orc_data *d, int g1, const double *c, double r, double margin, double *dist, double *pos,
+                       double *normal) {
+  const double *pm = d->geom_xmat + 9 * g1, *pp = d->geom_xpos + 3 * g1;
+  double n[3] = {pm[2], pm[5], pm[8]}, df[3];
+  sub3(df, c, pp);
+  double ds = dot3(df, n) - r;
+  if (ds > margin) return 0;
+  *dist = ds;
+  for (int k = 0; k < 3; k++) pos[k] = c[k] - (r + 0.5 * ds) * n[k];
+  memcpy(normal, n, 24);
+  return 1;
+}
+/* sphere (c1, r1) - sphere (c2, r2): mjc_SphereSphere's closed form; normal from 1 to 2 */
+static int sphere_sphere(const double *c1, double r1, const double *c2, double r2, double margin, double *dist, double *pos,
+                         double *normal) {
+  double df[3];
+  sub3(df, c2, c1);
+  double len = norm3(df);
+  if (len - r1 - r2 > margin) return 0;
+  if (len < 1e-15) { normal[0] = 1; normal[1] = normal[2] = 0; }
+  else for (int k = 0; k < 3; k++) normal[k] = df[k] / len;
+  *dist = len - r1 - r2;
+  for (int k = 0; k < 3; k++) pos[k] = c1[k] + (r1 + 0.5 * *dist) * normal[k];
+  return 1;
+}
+/* point of the segment c +- h * axis closest to p */
+static void seg_closest_point(const double *c, const double *axis, double h, const double *p, double *out) {
+  double df[3];
+  sub3(df, p, c);
+  double t = dot3(df, axis);
+  t = t > h ? h : (t < -h ? -h : t);
+  for (int k = 0; k < 3; k++) out[k] = c[k] + t * axis[k];
+}
+/* closest points of two segments c1 +- h1 a1, c2 +- h2 a2 (unit axes) */
+static void seg_seg_closest(const double *c1, const double *a1, double h1, const double *c2, const double *a2, double h2,
+                            double *p1, double *p2) {
+  double w[3];
+  sub3(w, c1, c2);
+  double b = dot3(a1, a2), d1 = dot3(a1, w), d2 = dot3(a2, w), den = 1 - b * b, t1, t2;
+  if (den > 1e-12) {
+    t1 = (b * d2 - d1) / den;
+    t1 = t1 > h1 ? h1 : (t1 < -h1 ? -h1 : t1);
+  } else t1 = 0; /* parallel axes: start from the middle of segment 1 */
+  t2 = b * t1 + d2;
+  if (t2 > h2 || t2 < -h2) {
+    t2 = t2 > h2 ? h2 : -h2;
+    t1 = b * t2 - d1;
+    t1 = t1 > h1 ? h1 : (t1 < -h1 ? -h1 : t1);
+  }
+  for (int k = 0; k < 3; k++) { p1[k] = c1[k] + t1 * a1[k]; p2[k] = c2[k] + t2 * a2[k]; }
+}
+
+/* contacts a candidate pair can produce (sub-contacts are numbered 0 .. n-1) */
+int orc_pair_nsub(const orc_model *m, int g1, int g2) {
+  int t1 = m->geom_type[g1], t2 = m->geom_type[g2];
+  if (t1 == GEOM_PLANE && t2 == GEOM_CAPSULE) return 2;
+  if (t1 == GEOM_PLANE && t2 == GEOM_BOX) return 8;
+  return 1;
+}
+/* sub-contact `sub` of the pair (g1, g2): 1 when it exists.  Counts MPR work in iters / npair. */
+static int narrow_sub(const orc_model *m, const orc_data *d, int g1, int g2, int sub, double margin, double *dist,
+                      double *pos, double *normal, int64_t *iters, int64_t *npair) {
+  int t1 = m->geom_type[g1], t2 = m->geom_type[g2];
+  const double *x1 = d->geom_xpos + 3 * g1, *x2 = d->geom_xpos + 3 * g2;
+  const double *R1 = d->geom_xmat + 9 * g1, *R2 = d->geom_xmat + 9 * g2;
+  const double *s1 = m->geom_size + 3 * g1, *s2 = m->geom_size + 3 * g2;
+  if (t1 == GEOM_HFIELD || t2 == GEOM_HFIELD || t2 == GEOM_PLANE) return 0;
+  if (t1 == GEOM_PLANE) {
+    if (t2 == GEOM_CAPSULE) { /* cap centre +axis first, then -axis */
+      double sg = sub == 0 ? s2[1] : -s2[1], c[3] = {x2[0] + sg * R2[2], x2[1] + sg * R2[5], x2[2] + sg * R2[8]};
+      return plane_point(d, g1, c, s2[0], margin, dist, pos, normal);
+    }
+    if (t2 == GEOM_BOX) { /* corner `sub`: bit 0 / 1 / 2 set = negative x / y / z side */
+      double v[3] = {sub & 1 ? -s2[0] : s2[0], sub & 2 ? -s2[1] : s2[1], sub & 4 ? -s2[2] : s2[2]}, c[3];
+      for (int r = 0; r < 3; r++) c[r] = x2[r] + R2[3 * r] * v[0] + R2[3 * r + 1] * v[1] + R2[3 * r + 2] * v[2];
+      return plane_point(d, g1, c, 0.0, margin, dist, pos, normal);
+    }
+    return plane_pair(m, d, g1, g2, margin, dist, pos, normal);
+  }
+  if (t1 == GEOM_SPHERE && t2 == GEOM_SPHERE) return sphere_sphere(x1, s1[0], x2, s2[0], margin, dist, pos, normal);
+  if (t1 == GEOM_SPHERE && t2 == GEOM_CAPSULE) {
+    double ax[3] = {R2[2], R2[5], R2[8]}, p[3];
+    seg_closest_point(x2, ax, s2[1], x1, p);
+    return sphere_sphere(x1, s1[0], p, s2[0], margin, dist, pos, normal);
+  }
+  if (t1 == GEOM_CAPSULE && t2 == GEOM_CAPSULE) {
+    double a1[3] = {R1[2], R1[5], R1[8]}, a2[3] = {R2[2], R2[5], R2[8]}, p1[3], p2[3];
+    seg_seg_closest(x1, a1, s1[1], x2, a2, s2[1], p1, p2);
+    return sphere_sphere(p1, s1[0], p2, s2[0], margin, dist, pos, normal);
+  }
+  (*npair)++;
+  return convex_pair(m, d, g1, g2, margin, dist, pos, normal, iters);
+}
 
 int orc_narrow_pair(const orc_model *m, const orc_data *d, int g1, int g2, double margin, double *dist,
                     double *pos, double *normal) {
-  int64_t it = 0;
-  if (m->geom_type[g1] == GEOM_PLANE && m->geom_type[g2] == GEOM_MESH)
-    return plane_pair(m, d, g1, g2, margin, dist, pos, normal);
-  if (m->geom_type[g1] == GEOM_MESH && m->geom_type[g2] == GEOM_MESH)
-    return convex_pair(m, d, g1, g2, margin, dist, pos, normal, &it);
-  return 0;
+  int64_t it = 0, np = 0;
+  return narrow_sub(m, d, g1, g2, 0, margin, dist, pos, normal, &it, &np);
 }
 
 void orc_collision(const orc_model *m, orc_data *d) {
   d->ncon = 0;
   if (m->disableflags & DSBL_CONTACT) return;
-  for (int p = 0; p < m->npair; p++) {
+  int full = 0;
+  for (int p = 0; p < m->npair && !full; p++) {
     int g1 = m->pair_geom1[p], g2 = m->pair_geom2[p];
     double margin = fmax(m->geom_margin[g1], m->geom_margin[g2]);
     double gap = fmax(m->geom_gap[g1], m->geom_gap[g2]);
-    int t1 = m->geom_type[g1], t2 = m->geom_type[g2];
+    int t1 = m->geom_type[g1];
     /* broadphase: bounding spheres (a plane has rbound 0: sphere-plane test instead) */
     if (m->geom_rbound[g1] > 0 && m->geom_rbound[g2] > 0) {
       double df[3];
@@ -362,15 +501,11 @@ void orc_collision(const orc_model *m, orc_data *d) {
       sub3(df, d->geom_xpos + 3 * g2, d->geom_xpos + 3 * g1);
       if (dot3(df, n) > margin + m->geom_rbound[g2]) continue;
     }
+    const int nsub = orc_pair_nsub(m, g1, g2);
+    for (int sub = 0; sub < nsub; sub++) {
     double dist, pos[3], nrm[3];
-    int hit;
-    if (t1 == GEOM_PLANE && t2 == GEOM_MESH) hit = plane_pair(m, d, g1, g2, margin, &dist, pos, nrm);
-    else if (t1 == GEOM_MESH && t2 == GEOM_MESH) {
-      d->stat_npair_narrow++;
-      hit = convex_pair(m, d, g1, g2, margin, &dist, pos, nrm, &d->stat_mpr_iter);
-    } else continue; /* other geom types are outside the exporter's dialect */
-    if (!hit) continue;
-    if (d->ncon >= ORC_MAXCON) { d->warning |= 8; break; }
+    if (!narrow_sub(m, d, g1, g2, sub, margin, &dist, pos, nrm, &d->stat_mpr_iter, &d->stat_npair_narrow)) continue;
+    if (d->ncon >= ORC_MAXCON) { d->warning |= 8; full = 1; break; }
     orc_contact *c = d->contact + d->ncon++;
     memset(c, 0, sizeof *c);
     c->dist = dist;
@@ -391,5 +526,6 @@ void orc_collision(const orc_model *m, orc_data *d) {
     for (int k = 0; k < 2; k++) c->solref[k] = mix * m->geom_solref[2 * g1 + k] + (1 - mix) * m->geom_solref[2 * g2 + k];
     for (int k = 0; k < 5; k++) c->solimp[k] = mix * m->geom_solimp[5 * g1 + k] + (1 - mix) * m->geom_solimp[5 * g2 + k];
     c->efc_address = -1;
+    }
   }
 }
