@@ -1111,9 +1111,11 @@ extern "C" int bs_forward(bs_sim* s) {
     const int rc = ensure_serial_contact(s);  // bs_forward writes every intermediate: serial pipeline
     if (rc) return rc;
     launch_contact_pass(s, 0, 0);
-  } else if (s->use_tp && s->dm.solver == 2)
-    bs_launch_tp_full(grid_tp(s), 0, s->stream, s->dm, s->tp, s->dd, 1, 1, 2);
-  else
+  } else if (s->use_tp) {
+    auto* launch = s->dm.solver == 0 ? bs_launch_tp_full_pgs : s->dm.solver == 1 ? bs_launch_tp_full_cg : bs_launch_tp_full;
+    launch(grid_tp(s), s->dm.solver == 0 ? (size_t)2 * s->dm.nbody * tp_minv_stride(s->dm.nbody) * sizeof(double) : 0, s->stream,
+           s->dm, s->tp, s->dd, 1, 1, 2);
+  } else
     bs_launch_forward(grid_for(s), s->stream, s->dm, s->dd);
   HIPCHK(hipGetLastError());
   return BS_OK;

@@ -43,6 +43,10 @@ TP_KERNEL(tp_rk4_cg, false, false, true, true, false, false, false)
 TP_KERNEL(tp_rk4_pgs, false, false, true, false, true, false, true)
 #elif defined(TPK_tp_full)
 TP_KERNEL(tp_full, false, true, false, false, false, false, false)
+#elif defined(TPK_tp_full_cg)
+TP_KERNEL(tp_full_cg, false, true, false, true, false, false, false)
+#elif defined(TPK_tp_full_pgs)
+TP_KERNEL(tp_full_pgs, false, true, false, false, true, false, true)
 #elif defined(TPK_tp_col)
 // kinematics + geom frames + broadphase, tree-parallel layout (physics_tp.h::tp_collide_prep)
 __global__ __launch_bounds__(64) void k_tp_col(DevModel m, TpModel t, DevData d, ColModel cm, ColData cd) {

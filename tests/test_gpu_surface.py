@@ -214,3 +214,38 @@ def test_check_acc_paths_pinned(hand_model, monkeypatch):
             assert t[3] == 0.0 and np.abs(qv[3]).max() == 0, label  # reset, integration skipped
     assert np.allclose(out["cf_tp"][2][3], out["cf_serial"][2][3], atol=1e-12)
     assert np.array_equal(out["con_tp"][2][3], out["con_serial"][2][3])
+
+
+@pytest.mark.parametrize("solver", ["cg", "pgs"])
+def test_forward_cg_pgs_on_tree_parallel_kernels(hand_model, solver, monkeypatch):
+    """bs_forward with CG / PGS runs k_tp_full_cg / k_tp_full_pgs (round 1: serial kernels only):
+    the full dump against the serial kernels and the oracle."""
+    import torch
+    from mujoco_amd import BatchSim, workload
+    from mujoco_amd.model import SOL_CG, SOL_PGS
+    from oracle import OracleSim
+    m = workload.contact_free(hand_model)
+    m.opt_solver = SOL_CG if solver == "cg" else SOL_PGS
+    E = 66
+    q, v = workload.config2_state(m, E, seed=8)
+    v = np.random.default_rng(8).normal(size=v.shape) * 0.3
+    c = workload.config2_ctrl(m, E, seed=8)
+    res = {}
+    for kern in ("tp", "serial"):
+        monkeypatch.setenv("BS_KERNEL", kern)
+        sim = BatchSim(m, n_envs=E)
+        sim.data.qpos.copy_(torch.as_tensor(q)); sim.data.qvel.copy_(torch.as_tensor(v)); sim.data.ctrl.copy_(torch.as_tensor(c))
+        sim.forward(); sim.sync()
+        res[kern] = {f: getattr(sim.data, f).cpu().numpy().copy() for f in
+                     ("qacc", "qfrc_constraint", "efc_force", "efc_D", "efc_aref", "qM", "qLD", "cinert", "solver_iter", "nefc")}
+    monkeypatch.delenv("BS_KERNEL")
+    a, b = res["tp"], res["serial"]
+    assert (a["nefc"] == b["nefc"]).all() and np.abs(a["solver_iter"].astype(int) - b["solver_iter"].astype(int)).max() <= 1
+    for f, tol in (("qM", 1e-12), ("qLD", 1e-10), ("cinert", 1e-12), ("efc_D", 1e-12), ("efc_aref", 1e-10), ("qacc", 1e-6),
+                   ("qfrc_constraint", 1e-6), ("efc_force", 1e-6)):
+        assert np.abs(a[f] - b[f]).max() <= tol * max(1.0, np.abs(b[f]).max()), f
+    for e in range(0, E, 11):
+        s = OracleSim(m)
+        s.qpos[:] = q[e]; s.qvel[:] = v[e]; s.ctrl[:] = c[e]
+        s.forward()
+        assert np.abs(a["qacc"][e] - s.qacc).max() / max(1.0, np.abs(s.qacc).max()) < 1e-8, e
