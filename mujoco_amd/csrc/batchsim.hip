@@ -642,6 +642,7 @@ struct bs_sim {
   TpModel tp;
   bool use_tp = false;
   bool narrow_ws = false, narrow_blocks = false;
+  int nl_grid = 4096;  // wavefronts of the persistent narrowphase (k_c_narrow_list)
   bool use_tpc = false;  // contacts: tree-parallel dynamics kernel instead of the serial k_c_dyn (steps only)
   bool contacts = false;
   ColModel cm;
@@ -736,7 +737,8 @@ static void launch_tpc_pass(bs_sim* s, const DevData& dd, hipStream_t st, int mo
     launch_narrow(s, dd, st);
   } else {
     size_t nb = ((size_t)(dd.n_envs - dd.env0) * s->cm.maxcand + NL_THREADS - 1) / NL_THREADS;
-    nb = nb < 1 ? 1 : nb > 16384 ? 16384 : nb;
+    const size_t cap = s->cm.has_prim ? 16384 : (size_t)s->nl_grid;
+    nb = nb < 1 ? 1 : nb > cap ? cap : nb;
     bs_launch_narrow_list(dim3((unsigned)nb), st, s->cm, dd, s->cd, s->cm.has_prim);
   }
   const int ntri = s->dm.nbody * (s->dm.nbody + 1) / 2;
@@ -891,6 +893,10 @@ extern "C" int bs_sim_create(const bs_model* const* models, int n_models, const 
     const char* nk = getenv("BS_NARROW");
     s->narrow_ws = nk && strcmp(nk, "ws") == 0 && !s->cm.has_prim;  // the work-stealing variant knows hulls and planes only
     s->narrow_blocks = nk && strcmp(nk, "blocks") == 0;
+    const char* sh = getenv("BS_NL_SHARE");  // tuning knobs of the persistent narrowphase
+    s->cm.nl_min_share = sh && atoi(sh) > 0 ? atoi(sh) : NL_MIN_SHARE;
+    const char* gr = getenv("BS_NL_GRID");
+    if (gr && atoi(gr) > 0) s->nl_grid = atoi(gr);
   }
   if (kv && strcmp(kv, "tp") == 0 && !model->tp_ok) {
     delete s;

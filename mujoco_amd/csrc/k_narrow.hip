@@ -94,15 +94,24 @@ __global__ __launch_bounds__(NL_THREADS) void k_c_narrow_list(ColModel cm, DevDa
   const int* items = c.items + col_items_base(d.env0, d.range, cm.maxcand);
   const long subcap = col_items_subcap(d.n_envs - d.env0, cm.maxcand);
   unsigned acc[2] = {0, 0};
-  for (unsigned i = blockIdx.x * NL_THREADS + tid; i < total; i += gridDim.x * NL_THREADS) {
-    int lo = 0, hi = BS_NSUB;  // sub-list of item i: largest s with pre[s] <= i
-    while (hi - lo > 1) {
-      const int mid = (lo + hi) >> 1;
-      if (pre[mid] <= i) lo = mid;
-      else hi = mid;
+  if constexpr (!PRIM) {
+    // every wavefront owns an equal share of the list and its lanes take items from it as they finish
+    const unsigned nw = gridDim.x * (NL_THREADS / 64), w = blockIdx.x * (NL_THREADS / 64) + tid / 64;
+    unsigned share = (total + nw - 1) / nw;
+    if (share < (unsigned)cm.nl_min_share) share = (unsigned)cm.nl_min_share;  // a few items per lane, or the lanes idle in the range's tail
+    const unsigned first = w * share < total ? w * share : total, last = first + share < total ? first + share : total;
+    col_narrow_persistent(cm, d, c, first, last, pre, items, subcap, acc, mpr[tid]);
+  } else {
+    for (unsigned i = blockIdx.x * NL_THREADS + tid; i < total; i += gridDim.x * NL_THREADS) {
+      int lo = 0, hi = BS_NSUB;  // sub-list of item i: largest s with pre[s] <= i
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (pre[mid] <= i) lo = mid;
+        else hi = mid;
+      }
+      const int it = items[lo * subcap + (i - pre[lo])];
+      col_narrowphase<PRIM>(cm, d, c, d.env0 + (it >> 8), it & 255, acc, mpr[tid]);
     }
-    const int it = items[lo * subcap + (i - pre[lo])];
-    col_narrowphase<PRIM>(cm, d, c, d.env0 + (it >> 8), it & 255, acc, mpr[tid]);
   }
   if (c.stat) {
     for (int off = 32; off > 0; off >>= 1) {

@@ -3,9 +3,12 @@
 // instantiations (each a few thousand lines of straight-line fp64 code) build in parallel.
 // Block = one 64-lane wavefront = two environments; __launch_bounds__(64, 2) = two waves per SIMD.
 #include "kernels.h"
+#ifndef TP_OCC
+#define TP_OCC 2
+#endif
 
 #define TP_KERNEL(name, CONTACTS_, FULL_, RK4_, CG_, PGS_, PARK_, MINV_)                                              \
-  __global__ __launch_bounds__(64, 2) void k_##name(DevModel m, TpModel t, DevData d, int nsteps, int mode, int dump) { \
+  __global__ __launch_bounds__(64, TP_OCC) void k_##name(DevModel m, TpModel t, DevData d, int nsteps, int mode, int dump) { \
     __shared__ int tbl[TPL_TOTAL * 64];                                                                               \
     __shared__ double park[PARK_ ? (TP_MAXD + 1) * 64 : 1];                                                           \
     extern __shared__ double minv[]; /* PGS: 2 x nbody x tp_minv_stride(nbody) */                                     \

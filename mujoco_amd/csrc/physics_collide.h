@@ -48,6 +48,7 @@ struct ColModel {
   const double *geom_obb; // [ngeom][6] box around the hull in the geom frame: centre, half extents (< 0: none)
   const double *geom_size; // [ngeom][3] mjModel.geom_size (primitives)
   const int *pair_nsub;    // [npair] sub-contacts a pair can produce (0: pair of unsupported geom types)
+  int nl_min_share;        // least number of work-list items a wavefront of k_c_narrow_list takes
   int has_prim;            // some pair involves a primitive geom: the narrowphase kernels' PRIM instantiation runs
 };
 
@@ -127,6 +128,9 @@ __device__ __forceinline__ int rec_id(double w) { return __double2loint(w) & 0xF
 __device__ __forceinline__ int rec_deg(double w) { return (__double2loint(w) >> 20) & 0xFFF; }
 __device__ __forceinline__ int rec_k0(double w) { return __double2hiint(w); }
 
+#ifndef MD_BATCH
+#define MD_BATCH 8  // neighbour records per trip of md_support's climb loop
+#endif
 struct CObj {
   int type;        // BS_GEOM_* (PRIM instantiations only)
   V3 size;         // geom_size (primitives)
@@ -190,7 +194,9 @@ __device__ inline V3 hull_support(CObj& o, const V3& dir) {
 // rule, same neighbour order, same comparisons) run in ONE loop — a lane climbs hull 1, then
 // hull 2, one batch of four neighbour records per iteration — so a wavefront pays for the longest
 // sum of the two climbs among its lanes, not for the longest climb on each hull
-__device__ inline Spt md_support(CObj& a, CObj& b, const V3& dir) {
+// only_b (per lane; plane items of the persistent narrowphase): hull 1 is not climbed — the lane enters
+// the loop in its second phase — and the result's v2 is what hull_support(b, -dir) returns
+__device__ inline Spt md_support(CObj& a, CObj& b, const V3& dir, bool only_b = false) {
   const V3 da = {a.R.a[0] * dir.x + a.R.a[3] * dir.y + a.R.a[6] * dir.z, a.R.a[1] * dir.x + a.R.a[4] * dir.y + a.R.a[7] * dir.z,
                  a.R.a[2] * dir.x + a.R.a[5] * dir.y + a.R.a[8] * dir.z};
   const V3 nd = neg(dir);
@@ -213,18 +219,36 @@ __device__ inline Spt md_support(CObj& a, CObj& b, const V3& dir) {
   }
   V3 d = da, besta = best;
   const double4* nbr = a.nbr4;  // one global record array for every hull
-  int second = 0, prev = rec_id(rec), imax = prev;
+  int second = 0;
+  if (only_b) { second = 1; d = db; vmax = vmax2; rec = rec2; best = best2; }
+  int prev = rec_id(rec), imax = prev;
   int k = rec_k0(rec), k1 = k + rec_deg(rec);
   for (;;) {
-    double4 p[4];
+    // up to MD_BATCH neighbour records per trip, all loads issued before the first comparison: a
+    // vertex of the usual degree (6) is scanned in ONE memory round trip.  The second half is only
+    // loaded by lanes whose vertex has more than four neighbours left (same order of comparisons as
+    // the four-at-a-time loop: bitwise the same climb).
+    double4 p[MD_BATCH];
 #pragma unroll
     for (int q = 0; q < 4; q++) p[q] = nbr[k + q < k1 ? k + q : k1 - 1];
+    const bool more = k + 4 < k1;
+    if (more) {
+#pragma unroll
+      for (int q = 4; q < MD_BATCH; q++) p[q] = nbr[k + q < k1 ? k + q : k1 - 1];
+    }
 #pragma unroll
     for (int q = 0; q < 4; q++) {
       const double val = p[q].x * d.x + p[q].y * d.y + p[q].z * d.z;
       if (val > vmax) { vmax = val; rec = p[q].w; imax = rec_id(rec); best = {p[q].x, p[q].y, p[q].z}; }
     }
-    k += 4;
+    if (more) {
+#pragma unroll
+      for (int q = 4; q < MD_BATCH; q++) {
+        const double val = p[q].x * d.x + p[q].y * d.y + p[q].z * d.z;
+        if (val > vmax) { vmax = val; rec = p[q].w; imax = rec_id(rec); best = {p[q].x, p[q].y, p[q].z}; }
+      }
+    }
+    k += MD_BATCH;
     if (k < k1) continue;          // more neighbours of this vertex
     if (imax != prev) {            // moved: scan the new vertex
       prev = imax; k = rec_k0(rec); k1 = k + rec_deg(rec);
@@ -733,6 +757,110 @@ __device__ inline void col_narrowphase(const ColModel& cm, const DevData& d, con
     AT(c.cand_dist, slot) = dist;
     AT(c.cand_pos, 3 * slot) = pos.x; AT(c.cand_pos, 3 * slot + 1) = pos.y; AT(c.cand_pos, 3 * slot + 2) = pos.z;
     AT(c.cand_nrm, 3 * slot) = nrm.x; AT(c.cand_nrm, 3 * slot + 1) = nrm.y; AT(c.cand_nrm, 3 * slot + 2) = nrm.z;
+  }
+}
+
+// A6, persistent-lane form (the default of the tree-parallel path): a wavefront owns the items
+// [first, last) of the work list; every lane runs ONE loop around the support call and, when its item
+// is finished, takes the next item of the wavefront's range inside that loop (a wave-uniform cursor
+// advanced by ballot / popcount: no atomics), so a lane whose pair separates after one support call
+// does not idle until the slowest pair of the wavefront has refined its portal.  A plane item is one
+// support call of the hull along -normal (its partner is a dummy hull whose climb ends at once).
+// Same arithmetic per item as col_narrowphase<false>: bitwise the same candidates.
+__device__ inline void col_narrow_persistent(const ColModel& cm, const DevData& d, const ColData& c, unsigned first,
+                                             unsigned last, const unsigned* pre, const int* items, long subcap,
+                                             unsigned* acc, MprState& M) {
+  const long E = d.E;
+  const int lane = threadIdx.x & 63;
+  const unsigned long long lower = (1ull << lane) - 1ull;
+  unsigned cursor = first;  // wave-uniform
+  bool busy = false, plane = false;
+  long e = 0;
+  int slot = 0, iters = 0;
+  double margin = 0;
+  V3 pn = {0, 0, 0}, pp = {0, 0, 0};
+  CObj a, b;
+  a.type = b.type = BS_GEOM_MESH; a.size = b.size = {0, 0, 0};
+  a.vert4 = b.vert4 = cm.hull_vert4; a.nbr4 = b.nbr4 = cm.hull_nbr4; a.start4 = b.start4 = cm.hull_start4;
+  a.cache = b.cache = 0; a.margin = b.margin = 0;
+  a.xpos = b.xpos = {0, 0, 0};
+  for (int k = 0; k < 9; k++) { a.R.a[k] = 0; b.R.a[k] = 0; }
+  for (;;) {
+    // ---- lanes without an item take the next ones of the wavefront's range
+    const unsigned long long need = __ballot(!busy);
+    if (need) {
+      const unsigned i = cursor + (unsigned)__popcll(need & lower);
+      cursor += (unsigned)__popcll(need);
+      if (!busy && i < last) {
+        int lo = 0, hi = BS_NSUB;  // sub-list of item i: largest s with pre[s] <= i
+        while (hi - lo > 1) {
+          const int mid = (lo + hi) >> 1;
+          if (pre[mid] <= i) lo = mid;
+          else hi = mid;
+        }
+        const int it = items[lo * subcap + (i - pre[lo])];
+        e = d.env0 + (it >> 8); slot = it & 255;
+        const int p = AT(c.cand_pair, slot) & BS_PAIR_MASK;
+        const int g1 = cm.pair_geom1[p], g2 = cm.pair_geom2[p];
+        margin = fmax(cm.geom_margin[g1], cm.geom_margin[g2]);
+        const int mb = cm.geom_dataid[g2];
+        b.vert4 = cm.hull_vert4 + cm.mesh_vertadr[mb];
+        b.start4 = cm.hull_start4 + (size_t)mb * BS_NSTART;
+        b.cache = 0;
+        b.xpos = {AT(c.geom_xpos, 3 * g2), AT(c.geom_xpos, 3 * g2 + 1), AT(c.geom_xpos, 3 * g2 + 2)};
+        for (int k = 0; k < 9; k++) b.R.a[k] = AT(c.geom_xmat, 9 * g2 + k);
+        plane = cm.geom_type[g1] == BS_GEOM_PLANE;
+        iters = 0;
+        if (plane) {
+          pn = {AT(c.geom_xmat, 9 * g1 + 2), AT(c.geom_xmat, 9 * g1 + 5), AT(c.geom_xmat, 9 * g1 + 8)};
+          pp = {AT(c.geom_xpos, 3 * g1), AT(c.geom_xpos, 3 * g1 + 1), AT(c.geom_xpos, 3 * g1 + 2)};
+          b.margin = 0;
+          // the partner is not climbed (md_support's only_b): it points at the same hull so its start loads are valid
+          a.vert4 = b.vert4; a.start4 = b.start4; a.cache = 0; a.margin = 0;
+          M.d = pn;  // the hull is queried along -d
+        } else {
+          const int ma = cm.geom_dataid[g1];
+          a.vert4 = cm.hull_vert4 + cm.mesh_vertadr[ma];
+          a.start4 = cm.hull_start4 + (size_t)ma * BS_NSTART;
+          a.cache = 0;
+          a.xpos = {AT(c.geom_xpos, 3 * g1), AT(c.geom_xpos, 3 * g1 + 1), AT(c.geom_xpos, 3 * g1 + 2)};
+          for (int k = 0; k < 9; k++) a.R.a[k] = AT(c.geom_xmat, 9 * g1 + k);
+          a.margin = 0.5 * margin; b.margin = 0.5 * margin;
+          mpr_begin(M, a.xpos, b.xpos);
+        }
+        busy = true;
+      }
+    }
+    if (!__ballot(busy)) break;
+    if (busy) {
+      const Spt s = md_support(a, b, M.d, plane);
+      bool fin, hit = false;
+      double dist = 0;
+      V3 pos = {0, 0, 0}, nrm = {0, 0, 0};
+      if (plane) {
+        fin = true;
+        const double ds = dot(sub(s.v2, pp), pn);
+        if (!(ds > margin)) {
+          hit = true; dist = ds; nrm = pn;
+          pos = {s.v2.x - 0.5 * ds * pn.x, s.v2.y - 0.5 * ds * pn.y, s.v2.z - 0.5 * ds * pn.z};
+        }
+      } else {
+        double depth = 0;
+        const int r = mpr_step(M, s, a.xpos, b.xpos, cm.mpr_tolerance, cm.mpr_iterations, depth, nrm, pos, iters);
+        fin = r != 0;
+        if (r == 1 && !(nrm.x == 0 && nrm.y == 0 && nrm.z == 0)) { hit = true; dist = margin - depth; }
+        if (fin) { acc[0] += 1; acc[1] += (unsigned)iters; }
+      }
+      if (fin) {
+        AT(c.cand_hit, slot) = hit ? 1 : 0;
+        if (hit) {
+          AT(c.cand_dist, slot) = dist;
+          AT(c.cand_pos, 3 * slot) = pos.x; AT(c.cand_pos, 3 * slot + 1) = pos.y; AT(c.cand_pos, 3 * slot + 2) = pos.z;
+          AT(c.cand_nrm, 3 * slot) = nrm.x; AT(c.cand_nrm, 3 * slot + 1) = nrm.y; AT(c.cand_nrm, 3 * slot + 2) = nrm.z;
+        }
+        busy = false;
+      }
+    }
   }
 }
 

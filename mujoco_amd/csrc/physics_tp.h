@@ -83,10 +83,14 @@ __device__ __forceinline__ double dpp_mov(double v) {
   const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
   return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ double swz16(double v) {  // lane ^ 16 inside each 32-lane half
-  const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(v), 0x401F);
-  const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(v), 0x401F);
-  return __hiloint2double(hi, lo);
+// v(lane) + v(lane ^ 16) inside each 32-lane half with gfx950's v_permlane16_swap (a VALU instruction:
+// no trip through the LDS pipe as ds_swizzle takes).  The swap of a register with itself leaves row r0 =
+// rows {0, 0, 2, 2} and r1 = rows {1, 1, 3, 3} of the input, so r0 + r1 has the same operands in the same
+// order in both rows of a half: the bitwise-same sum in every lane.
+__device__ __forceinline__ double sum16(double v) {
+  const auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(v), __double2loint(v), false, false);
+  const auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(v), __double2hiint(v), false, false);
+  return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
 }
 // all-reduce over the 32 lanes of an environment; every lane gets the bitwise-same sum
 __device__ __forceinline__ double env_sum(double v) {
@@ -99,16 +103,15 @@ __device__ __forceinline__ double env_sum(double v) {
   v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
   v += dpp_mov<0x141>(v);  // row_half_mirror
   v += dpp_mov<0x140>(v);  // row_mirror
-  v += swz16(v);
-  return v;
+  return sum16(v);
 }
 __device__ __forceinline__ int env_sum_i(int v) {
   v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);
   v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);
   v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false);
   v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false);
-  v += __builtin_amdgcn_ds_swizzle(v, 0x401F);
-  return v;
+  const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+  return (int)(r[0] + r[1]);
 }
 __device__ __forceinline__ bool env_any(bool p, int base) {
   const unsigned long long b = __ballot(p);
