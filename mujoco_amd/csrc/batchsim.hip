@@ -976,7 +976,7 @@ extern "C" int bs_sim_create(const bs_model* const* models, int n_models, const 
     const size_t mc = (size_t)s->cm.maxcand, mk = (size_t)s->cm.maxcon;
     const size_t drows = mc * 7 + mk * 13;
     const size_t irows = 1 + mc * 2 + 1 + mk + 1 + mk;
-    const size_t nstat = BS_STAT_ITEMS + 4 * BS_NSUB;                 // counters (8 bytes each)
+    const size_t nstat = BS_STAT_CON + BS_NSUB;                        // counters (8 bytes each)
     const size_t nitems = mc * ((size_t)E + 4 * 2 * BS_NSUB);         // narrowphase work list, 4 ranges at most
     const size_t bytes = drows * E * sizeof(double) + irows * E * sizeof(int) + 16 + nstat * 8 + nitems * sizeof(int);
     he = hipMalloc(&s->carena, bytes);
@@ -1381,6 +1381,12 @@ extern "C" int bs_collision_stats(bs_sim* s, uint64_t out[3], int reset) {
   HIPCHK(hipSetDevice(s->device));
   HIPCHK(hipStreamSynchronize(s->stream));
   HIPCHK(hipMemcpy(out, s->cd.stat, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  {
+    uint64_t part[BS_NSUB];  // the tree-parallel kernels count contacts on BS_NSUB addresses
+    HIPCHK(hipMemcpy(part, s->cd.stat + BS_STAT_CON, sizeof part, hipMemcpyDeviceToHost));
+    for (int q = 0; q < BS_NSUB; q++) out[2] += part[q];
+    if (reset) HIPCHK(hipMemset(s->cd.stat + BS_STAT_CON, 0, sizeof part));
+  }
 #ifdef NP_PROFILE
   bs_np_profile_dump();
 #endif

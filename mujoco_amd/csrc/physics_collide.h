@@ -95,6 +95,7 @@ struct ColData {
   unsigned long long *stat;  // [0] narrow pairs, [1] mpr iterations, [2] contacts
 #define BS_STAT_ITEMS 32
 #define BS_NSUB 64
+#define BS_STAT_CON (BS_STAT_ITEMS + 4 * BS_NSUB)  // contact counter of the tree-parallel kernels, spread over BS_NSUB addresses
 };
 // capacity of one sub-list: the environments of ceil(blocks / BS_NSUB) broadphase blocks (2 each)
 __host__ __device__ inline long col_items_subcap(long nenv, int maxcand) {

@@ -1187,6 +1187,32 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
           }
         }
       };
+      // the same for two vectors at once: one trip down the tree carries both
+      auto con_jx2 = [&](double x0, double x1, double* u3a, double* u3b) {
+        if constexpr (CON) {
+          double cv[12];
+#pragma unroll
+          for (int k = 0; k < 6; k++) { cv[k] = isb ? cdof[k] * x0 : 0.0; cv[6 + k] = isb ? cdof[k] * x1 : 0.0; }
+          tp_chain_sum<12>(cv, par_sa, t.jump_rounds, isb);
+#pragma unroll
+          for (int h2 = 0; h2 < 2; h2++) {
+            double v1[6], v2[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) { v1[k] = bperm(cv[6 * h2 + k], b1_sa); v2[k] = bperm(cv[6 * h2 + k], b2_sa); }
+            double* u3 = h2 ? u3b : u3a;
+            u3[0] = u3[1] = u3[2] = 0;
+            if (cnr > 0) {
+              const V3 w1 = cross(V3{v1[0], v1[1], v1[2]}, off1), w2 = cross(V3{v2[0], v2[1], v2[2]}, off2);
+              const V3 rv = {(v2[3] + w2.x) - (v1[3] + w1.x), (v2[4] + w2.y) - (v1[4] + w1.y),
+                             (v2[5] + w2.z) - (v1[5] + w1.z)};
+              const tp_lds_d f = myslot + CG_FRAME;
+              u3[0] = f[0] * rv.x + f[1] * rv.y + f[2] * rv.z;
+              u3[1] = f[3] * rv.x + f[4] * rv.y + f[5] * rv.z;
+              u3[2] = f[6] * rv.x + f[7] * rv.y + f[8] * rv.z;
+            }
+          }
+        }
+      };
       auto con_rows = [&](const double* u3, double sub, double* out) {
         out[0] = cnr > 0 ? (u3[0] + cmu * u3[1]) - sub * caref[0] : 0.0;
         out[1] = cnr > 1 ? (u3[0] - cmu * u3[1]) - sub * caref[1] : 0.0;
@@ -1225,7 +1251,7 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
             for (int k = 0; k < 9; k++) sl[CG_FRAME + k] = fr[k];
             sl[CG_DIST] = dist;
             ((tp_lds_i)(sl + CG_PAIR))[0] = pr;
-            if (env_ok) {
+            if (env_ok && dump >= 1) {  // the contact list is an output: written by the last pass of a launch sequence only
               AT(cd.con_pair, n) = pr; AT(cd.con_dist, n) = dist;
               AT(cd.con_pos, 3 * n) = p.x; AT(cd.con_pos, 3 * n + 1) = p.y; AT(cd.con_pos, 3 * n + 2) = p.z;
 #pragma unroll
@@ -1237,7 +1263,7 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
         if (count > cm.maxcon) { count = cm.maxcon; warning |= 8; }
         if (env_ok && l == 0) {
           AT(cd.ncon, 0) = count;
-          if (cd.stat && count) atomicAdd(cd.stat + 2, (unsigned long long)count);
+          if (cd.stat && count) atomicAdd(cd.stat + BS_STAT_CON + (blockIdx.x & (BS_NSUB - 1)), (unsigned long long)count);
         }
         tp_wave_sync();
         double cB = 0, ckimp = 0;
@@ -1636,10 +1662,13 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
         TpSol s;
 #pragma unroll
         for (int q = 0; q < 4; q++) { s.cj[q] = 0; s.cv[q] = 0; }
-        auto residual = [&](double a, double sub, double& jf, double& jl0, double& jl1, double& je, double* cjr) {
+        auto residual_fixed = [&](double a, double sub, double& jf, double& jl0, double& jl1, double& je) {
           const double ao = bperm(a, eq_other_sa);
           jf = a - sub * r.aref_f; jl0 = a - sub * r.aref_l0; jl1 = -a - sub * r.aref_l1;
           je = r.own ? (a - r.ce * ao) - sub * r.aref_e : 0.0;
+        };
+        auto residual = [&](double a, double sub, double& jf, double& jl0, double& jl1, double& je, double* cjr) {
+          residual_fixed(a, sub, jf, jl0, jl1, je);
           if constexpr (CON) {
             double u3[3];
             con_jx(a, u3);
@@ -1648,23 +1677,43 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
         };
         // warm start: previous acceleration only if cheaper than the unconstrained one
         // (M qacc_smooth == qfrc_smooth, so its Gauss term vanishes and Ma is known)
+        // warm start: the residuals of the previous acceleration and of the unconstrained one in ONE pass
+        // (with contacts the two vectors ride down the body tree together), the cheaper candidate's
+        // residuals are kept — no third evaluation
         bool use_smooth = true;
-        if (!(m.disableflags & BS_DSBL_WARMSTART)) {
-          double jf, jl0, jl1, je, cjt[4] = {0, 0, 0, 0};
-          residual(qacc_ws, 1.0, jf, jl0, jl1, je, cjt);
-          double cl = tp_rows_cost<false>(r, jf, jl0, jl1, je, nullptr) +
-                      0.5 * (Ma_ws - qfrc_smooth) * (qacc_ws - qacc_smooth);
-          if constexpr (CON) cl += tp_con_cost<false>(r.cD, cjt, nullptr);
-          const double cw = env_sum(cl);
-          residual(qacc_smooth, 1.0, jf, jl0, jl1, je, cjt);
-          cl = tp_rows_cost<false>(r, jf, jl0, jl1, je, nullptr);
-          if constexpr (CON) cl += tp_con_cost<false>(r.cD, cjt, nullptr);
-          const double cs = env_sum(cl);
-          use_smooth = cw > cs;
+        {
+          double wf, wl0, wl1, we, wc[4] = {0, 0, 0, 0};
+          const bool ws_on = !(m.disableflags & BS_DSBL_WARMSTART);
+          if (CON && ws_on) {
+            residual_fixed(qacc_smooth, 1.0, s.jf, s.jl0, s.jl1, s.je);
+            residual_fixed(qacc_ws, 1.0, wf, wl0, wl1, we);
+            double ua[3], ub[3];
+            con_jx2(qacc_smooth, qacc_ws, ua, ub);
+            con_rows(ua, 1.0, s.cj);
+            con_rows(ub, 1.0, wc);
+          } else {
+            residual(qacc_smooth, 1.0, s.jf, s.jl0, s.jl1, s.je, s.cj);
+            if (ws_on) residual(qacc_ws, 1.0, wf, wl0, wl1, we, wc);
+          }
+          if (ws_on) {
+            double cl = tp_rows_cost<false>(r, wf, wl0, wl1, we, nullptr) +
+                        0.5 * (Ma_ws - qfrc_smooth) * (qacc_ws - qacc_smooth);
+            if constexpr (CON) cl += tp_con_cost<false>(r.cD, wc, nullptr);
+            const double cw = env_sum(cl);
+            cl = tp_rows_cost<false>(r, s.jf, s.jl0, s.jl1, s.je, nullptr);
+            if constexpr (CON) cl += tp_con_cost<false>(r.cD, s.cj, nullptr);
+            const double cs = env_sum(cl);
+            use_smooth = cw > cs;
+            if (!use_smooth) {
+              s.jf = wf; s.jl0 = wl0; s.jl1 = wl1; s.je = we;
+              if constexpr (CON)
+#pragma unroll
+                for (int q = 0; q < 4; q++) s.cj[q] = wc[q];
+            }
+          }
         }
         s.qacc = has_dof ? (use_smooth ? qacc_smooth : qacc_ws) : 0.0;
         s.Ma = use_smooth ? qfrc_smooth : Ma_ws;
-        residual(s.qacc, 1.0, s.jf, s.jl0, s.jl1, s.je, s.cj);
         double gauss = 0, cost = 0, oldcost = 0;
         double cg_grad = 0, cg_Mgrad = 0;  // CG: gradient and M^-1 gradient of the previous iteration
         int iter = 0;
