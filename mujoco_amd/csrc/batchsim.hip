@@ -742,6 +742,11 @@ static void launch_tpc_pass(bs_sim* s, const DevData& dd, hipStream_t st, int mo
     bs_launch_narrow_list(dim3((unsigned)nb), st, s->cm, dd, s->cd, s->cm.has_prim);
   }
   const int ntri = s->dm.nbody * (s->dm.nbody + 1) / 2;
+  if (s->dm.solver == 0) {
+    const size_t lds = (size_t)(2 * TP_LPE * TPC_SLOT_PGS + 2 * TP_LPE * 3 + 2 * s->dm.nbody * tp_minv_stride(s->dm.nbody)) * sizeof(double);
+    bs_launch_tpc_pgs(g, lds, st, s->dm, s->tp, dd, s->cm, s->cd, mode, dump);
+    return;
+  }
   const size_t lds = (size_t)(2 * ntri + 2 * TP_LPE * TPC_SLOT + 2 * TP_LPE * 3) * sizeof(double);
   (s->dm.solver == 1 ? bs_launch_tpc_cg : bs_launch_tpc)(g, lds, st, s->dm, s->tp, dd, s->cm, s->cd, mode, dump);
 }
@@ -886,7 +891,7 @@ extern "C" int bs_sim_create(const bs_model* const* models, int n_models, const 
   }
   // every solver with either integrator, with and without contacts (PGS with contacts: Euler)
   const bool serial = kv && strcmp(kv, "serial") == 0;
-  const bool tp_solver = model->d.solver == 2 || model->d.solver == 1;
+  const bool tp_solver = true;  // Newton, CG and PGS all have tree-parallel contact kernels
   s->use_tp = !contacts && model->tp_ok && !serial;
   s->use_tpc = contacts && tp_solver && model->tp_ok && s->cm.maxcon <= TP_LPE && !serial;
   {

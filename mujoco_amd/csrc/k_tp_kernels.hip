@@ -64,6 +64,20 @@ void bs_launch_tp_col(dim3 g, size_t lds, hipStream_t st, const DevModel& m, con
 TPC_KERNEL(tpc, false, false)
 #elif defined(TPK_tpc_cg)
 TPC_KERNEL(tpc_cg, true, false)
+#elif defined(TPK_tpc_pgs)
+// contacts, PGS: no Hessian; dynamic LDS = contact slots (wider: aref, forces, B per contact), the U staging rows,
+// then M^-1 of the two environments
+__global__ __launch_bounds__(64, TPC_OCC) void k_tpc_pgs(DevModel m, TpModel t, DevData d, ColModel cm, ColData cd, int mode,
+                                                   int dump) {
+  __shared__ int tbl[TPL_TOTAL * 64];
+  extern __shared__ double tpc_dyn[];
+  double* cg = tpc_dyn;
+  double* U = cg + 2 * TP_LPE * TPC_SLOT_PGS;
+  double* minv = U + 2 * TP_LPE * 3;
+  const TpShared sh = {tbl, nullptr, cg, U, nullptr, minv};
+  tp_run<true, false, false, false, true>(m, t, d, 1, mode, dump, sh, cm, cd);
+}
+void bs_launch_tpc_pgs(BS_TPC_ARGS) { hipLaunchKernelGGL(k_tpc_pgs, g, dim3(64), lds, st, m, t, d, cm, cd, mode, dump); }
 #else
 #error "compile with -DTPK_<kernel name> (see the Makefile)"
 #endif

@@ -174,7 +174,9 @@ typedef int __attribute__((address_space(3))) * tp_lds_i;
 #define TPC_SLOT 17                              // doubles per contact slot (odd stride)
 #define TPC_HTRI (TP_LPE * (TP_LPE + 1) / 2)     // packed lower-triangular Hessian, one per env
 #define TPC_NTRI ((TPC_HTRI + TP_LPE - 1) / TP_LPE)
-enum { CG_POS = 0, CG_FRAME = 3, CG_DIST = 12, CG_PAIR = 13, CG_D = 14, CG_MASK = 15, CG_MU = 16 };  // PAIR: pair id | active rows
+enum { CG_POS = 0, CG_FRAME = 3, CG_DIST = 12, CG_PAIR = 13, CG_D = 14, CG_MASK = 15, CG_MU = 16,  // PAIR: pair id | active rows (Newton) / row count (PGS)
+       CG_AREF = 17, CG_F = 21, CG_B = 25 };  // PGS only: aref and force of the 4 rows, B = U M^-1 U^T (nn, n1, n2, 11, 12, 22)
+#define TPC_SLOT_PGS 31                          // doubles per contact slot of k_tpc_pgs (odd stride)
 struct TpShared { int* tbl; double* H; double* cg; double* U; double* park; double* minv; };  // park: [TP_MAXD + 1][64] or null
 // per-environment M^-1 in LDS (PGS): nbody rows of (nbody | 1) doubles (odd stride: conflict-free columns)
 __host__ __device__ inline int tp_minv_stride(int nbody) { return nbody | 1; }
@@ -861,7 +863,7 @@ __device__ __forceinline__ void tp_collide_prep(const DevModel& m, const TpModel
 // contact assembly, pyramid rows owned by lanes, dense Hessian per environment in LDS.
 // CG: mj_solCG instead of mj_solNewton (same primal loop, line search and stopping rule; the search
 // direction is Polak-Ribiere in the M^-1 inner product, physics_dev.h::cg_gradient) — no Hessian.
-// PGS: mj_solPGS (dual, projected Gauss-Seidel; contact-free models only): M^-1 is formed column by
+// PGS: mj_solPGS (dual, projected Gauss-Seidel): M^-1 is formed column by
 // column in LDS, the sweep visits the rows in efc order, the owner lane of a row computes its new
 // force and broadcasts the change, every dof lane adds change * (M^-1 J^T)_i to its acceleration.
 template <bool CON, bool FULL, bool RK4, bool CG = false, bool PGS = false>
@@ -869,6 +871,7 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
                                        int mode, int dump, TpShared sh, const ColModel& cm, const ColData& cd) {
   int* tbl = sh.tbl;
   const int tid = threadIdx.x;
+  constexpr int SL = (CON && PGS) ? TPC_SLOT_PGS : TPC_SLOT;  // contact slot stride
 #ifdef TPC_PROFILE
   unsigned long long tacc[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = clock64();
 #endif
@@ -1160,7 +1163,7 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
       // pyramid rows of the contact this lane owns (same arithmetic as make_contact_rows)
       const bool con_on = !(m.disableflags & BS_DSBL_CONSTRAINT);
       double caref[4] = {0, 0, 0, 0}, cmu = 0, cDrow = 0;
-      int cnr = 0, b1_sa = self_sa, b2_sa = self_sa;
+      int cnr = 0, b1_sa = self_sa, b2_sa = self_sa, ncon_env = 0;
       V3 off1 = {0, 0, 0}, off2 = {0, 0, 0};
       tp_lds_d slot0 = nullptr, myslot = nullptr, Hs = nullptr, Us = nullptr;
       // u3 = (normal, tangent1, tangent2) components of J_contact * x for the lane's contact:
@@ -1221,8 +1224,8 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
       };
       if constexpr (CON) {
         const int half = tid / TP_LPE;
-        slot0 = (tp_lds_d)sh.cg + half * (TP_LPE * TPC_SLOT);
-        myslot = slot0 + l * TPC_SLOT;
+        slot0 = (tp_lds_d)sh.cg + half * (TP_LPE * SL);
+        myslot = slot0 + l * SL;
         Hs = (tp_lds_d)sh.H + half * (m.nbody * (m.nbody + 1) / 2);
         Us = (tp_lds_d)sh.U + half * (TP_LPE * 3);
         const int ncand = AT(cd.ncand, 0);
@@ -1245,7 +1248,7 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
             y = normalized(V3{y.x - tt * x.x, y.y - tt * x.y, y.z - tt * x.z});
             const V3 z = cross(x, y);
             const double fr[9] = {x.x, x.y, x.z, y.x, y.y, y.z, z.x, z.y, z.z};
-            const tp_lds_d sl = slot0 + n * TPC_SLOT;
+            const tp_lds_d sl = slot0 + n * SL;
             sl[CG_POS] = p.x; sl[CG_POS + 1] = p.y; sl[CG_POS + 2] = p.z;
 #pragma unroll
             for (int k = 0; k < 9; k++) sl[CG_FRAME + k] = fr[k];
@@ -1261,6 +1264,7 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
           count += __popc(bits);
         }
         if (count > cm.maxcon) { count = cm.maxcon; warning |= 8; }
+        ncon_env = count;
         if (env_ok && l == 0) {
           AT(cd.ncon, 0) = count;
           if (cd.stat && count) atomicAdd(cd.stat + BS_STAT_CON + (blockIdx.x & (BS_NSUB - 1)), (unsigned long long)count);
@@ -1317,6 +1321,13 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
         con_rows(u3, 0.0, vel);
 #pragma unroll
         for (int q = 0; q < 4; q++) caref[q] = q < cnr ? -cB * vel[q] - ckimp : 0.0;
+        if constexpr (PGS) {
+          if (l < ncon_env) {
+            ((tp_lds_i)(myslot + CG_PAIR))[1] = cnr;  // rows of this contact (0: beyond its margin)
+#pragma unroll
+            for (int q = 0; q < 4; q++) { myslot[CG_AREF + q] = caref[q]; myslot[CG_F + q] = 0.0; }
+          }
+        }
         tp_wave_sync();
       }
 
@@ -1396,7 +1407,7 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
             const int sa = (base + ci) * 4;
             const V3 F = {bperm(Fw.x, sa), bperm(Fw.y, sa), bperm(Fw.z, sa)};
             if ((mine >> ci) & 1) {
-              const tp_lds_d sl = slot0 + ci * TPC_SLOT;
+              const tp_lds_d sl = slot0 + ci * SL;
               const int m1 = ((tp_lds_i)(sl + CG_MASK))[0], m2 = ((tp_lds_i)(sl + CG_MASK))[1];
               const int sgn = ((m2 >> l) & 1) - ((m1 >> l) & 1);
               if (sgn != 0) {
@@ -1442,7 +1453,7 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
           while (merged) {
             const int ci = __builtin_ctz(merged);
             merged &= merged - 1;
-            const tp_lds_d sl = slot0 + ci * TPC_SLOT;
+            const tp_lds_d sl = slot0 + ci * SL;
             double u0 = 0, u1 = 0, u2 = 0;
             unsigned chain = 0;
             if ((mine >> ci) & 1) {
@@ -1567,7 +1578,67 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
         const double ARf = mjj + (r.Df > 0 ? 1.0 / r.Df : 0.0), AR0 = mjj + (r.Dl0 > 0 ? 1.0 / r.Dl0 : 0.0),
                      AR1 = mjj + (r.Dl1 > 0 ? 1.0 / r.Dl1 : 0.0);
         const double ARe = r.own ? (Mrow[l] - r.ce * Mrow[ko]) - r.ce * (Orow[l] - r.ce * Orow[ko]) + 1.0 / r.De : 1.0;
+        // ---- contacts (k_tpc_pgs): U_c = Jacobian rows (normal, tangent1, tangent2) of contact c, one
+        // entry per dof lane, recomputed from the lane's motion axis where needed; w_q = M^-1 U_c[q]^T
+        // through the M^-1 rows in LDS; the 3x3 block B_c = U_c M^-1 U_c^T is formed once per step and
+        // kept in the contact's slot (it couples the four pyramid rows of the contact with each other)
+        const int half_ = tid / TP_LPE;
+        const unsigned long long conb = __ballot(CON && l < ncon_env);
+        const int ncon_max = CON ? (int)max(__popcll(conb & 0xffffffffull), __popcll(conb >> 32)) : 0;
+        auto con_u = [&](tp_lds_d sl, bool act, double& u0, double& u1, double& u2, unsigned& chain) {
+          u0 = u1 = u2 = 0; chain = 0;
+          if constexpr (CON) {
+            if (act) {
+              const int m1 = ((tp_lds_i)(sl + CG_MASK))[0], m2 = ((tp_lds_i)(sl + CG_MASK))[1];
+              chain = (unsigned)(m1 ^ m2);
+              const int sgn = ((m2 >> l) & 1) - ((m1 >> l) & 1);
+              if (sgn != 0) {
+                const V3 off = {sl[CG_POS] - com.x, sl[CG_POS + 1] - com.y, sl[CG_POS + 2] - com.z};
+                const V3 w = cross(V3{cdof[0], cdof[1], cdof[2]}, off);
+                const V3 v = {cdof[3] + w.x, cdof[4] + w.y, cdof[5] + w.z};
+                const tp_lds_d f = sl + CG_FRAME;
+                const double sg = sgn > 0 ? 1.0 : -1.0;
+                u0 = sg * (f[0] * v.x + f[1] * v.y + f[2] * v.z);
+                u1 = sg * (f[3] * v.x + f[4] * v.y + f[5] * v.z);
+                u2 = sg * (f[6] * v.x + f[7] * v.y + f[8] * v.z);
+              }
+            }
+          }
+        };
+        // w_q[l] = sum_k M^-1[l][k] U[q][k] over the dofs k of the two chains: U staged in LDS, M^-1 row of this lane
+        auto con_w = [&](double u0, double u1, double u2, unsigned chain, double& w0, double& w1, double& w2) {
+          w0 = w1 = w2 = 0;
+          if constexpr (CON) {
+            Us[3 * l] = u0; Us[3 * l + 1] = u1; Us[3 * l + 2] = u2;
+            tp_wave_sync();
+            if (l < m.nbody)
+              for (unsigned ch = chain; ch; ch &= ch - 1) {
+                const int k = __builtin_ctz(ch);
+                const double mk = Mrow[k];
+                w0 += mk * Us[3 * k]; w1 += mk * Us[3 * k + 1]; w2 += mk * Us[3 * k + 2];
+              }
+            tp_wave_sync();
+          }
+        };
+        if constexpr (CON) {
+          for (int ci = 0; ci < ncon_max; ci++) {
+            const tp_lds_d sl = slot0 + ci * SL;
+            const bool act = ci < ncon_env && ((tp_lds_i)(sl + CG_PAIR))[1] > 0;
+            double u0, u1, u2, w0, w1, w2;
+            unsigned chain;
+            con_u(sl, act, u0, u1, u2, chain);
+            con_w(u0, u1, u2, chain, w0, w1, w2);
+            const double bnn = env_sum(u0 * w0), bn1 = env_sum(u0 * w1), bn2 = env_sum(u0 * w2), b11 = env_sum(u1 * w1),
+                         b12 = env_sum(u1 * w2), b22 = env_sum(u2 * w2);
+            if (act && l == 0) {
+              sl[CG_B] = bnn; sl[CG_B + 1] = bn1; sl[CG_B + 2] = bn2; sl[CG_B + 3] = b11; sl[CG_B + 4] = b12; sl[CG_B + 5] = b22;
+            }
+          }
+          tp_wave_sync();
+        }
+        (void)half_;
         double fF = 0, fL0 = 0, fL1 = 0, fE = 0, acc = qacc_smooth;
+        double cfo[4] = {0, 0, 0, 0};  // forces of the contact this lane owns
         auto jtf = [&]() -> double {  // J^T f on this lane
           const double fo = bperm(fE, eq_src_sa);
           double q = fF + fL0 - fL1 + fE;
@@ -1582,15 +1653,38 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
           double f4[4];
           tp_rows_cost<true>(r, jf, jl0, jl1, je, f4);
           fF = r.Df > 0 ? f4[0] : 0.0; fL0 = r.Dl0 > 0 ? f4[1] : 0.0; fL1 = r.Dl1 > 0 ? f4[2] : 0.0; fE = r.own ? f4[3] : 0.0;
-          const double w = tp_solve(c, LM.R, LM.dinv, jtf());  // M^-1 J^T f
+          if constexpr (CON) {  // contact rows: f = -D min(J qacc_ws - aref, 0)
+            double u3[3], cjt[4];
+            con_jx(qacc_ws, u3);
+            con_rows(u3, 1.0, cjt);
+            tp_con_cost<true>(r.cD, cjt, cfo);
+          }
+          double jt = jtf();
+          if constexpr (CON) { jt += con_jtf(cfo); if (!has_dof) jt = 0; }
+          const double w = tp_solve(c, LM.R, LM.dinv, jt);  // M^-1 J^T f
           const double wo = bperm(w, eq_other_sa), so = bperm(qacc_smooth, eq_other_sa);
           double cl = 0;
+          if constexpr (CON) {
+            double ua[3], ub[3], jw[4], js[4];
+            con_jx2(w, qacc_smooth, ua, ub);
+            con_rows(ua, 0.0, jw);   // J_r w
+            con_rows(ub, 1.0, js);   // J_r qacc_smooth - aref_r
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+              if (q < cnr) cl += cfo[q] * (0.5 * (jw[q] + cfo[q] / r.cD) + js[q]);
+          }
           if (r.Df > 0) cl += fF * (0.5 * (w + fF / r.Df) + (qacc_smooth - r.aref_f));
           if (r.Dl0 > 0) cl += fL0 * (0.5 * (w + fL0 / r.Dl0) + (qacc_smooth - r.aref_l0));
           if (r.Dl1 > 0) cl += fL1 * (0.5 * (-w + fL1 / r.Dl1) + (-qacc_smooth - r.aref_l1));
           if (r.own) cl += fE * (0.5 * ((w - r.ce * wo) + fE / r.De) + ((qacc_smooth - r.ce * so) - r.aref_e));
-          if (env_sum(cl) > 0) { fF = fL0 = fL1 = fE = 0; }
+          if (env_sum(cl) > 0) { fF = fL0 = fL1 = fE = 0; cfo[0] = cfo[1] = cfo[2] = cfo[3] = 0; }
           else acc = qacc_smooth + w;
+          if constexpr (CON) {
+            if (l < ncon_env)
+#pragma unroll
+              for (int q = 0; q < 4; q++) myslot[CG_F + q] = cfo[q];
+            tp_wave_sync();
+          }
         }
         const unsigned actF = (unsigned)(__ballot(r.Df > 0) >> base), act0 = (unsigned)(__ballot(r.Dl0 > 0) >> base),
                        act1 = (unsigned)(__ballot(r.Dl1 > 0) >> base), actE = (unsigned)(__ballot(r.own) >> base);
@@ -1648,6 +1742,47 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
             if ((act0 >> ol) & 1) row(2, ol, improvement);
             if ((act1 >> ol) & 1) row(3, ol, improvement);
           }
+          if constexpr (CON) {
+            // contact rows, in contact order: every lane of the environment updates the (up to) four
+            // rows of contact ci with the same arithmetic (J_r acc from three environment-wide sums,
+            // the rows' coupling through B_c), then adds the force change times M^-1 U_c^T to its acceleration
+            for (int ci = 0; ci < ncon_max; ci++) {
+              const tp_lds_d sl = slot0 + ci * SL;
+              const int nr = ci < ncon_env ? ((tp_lds_i)(sl + CG_PAIR))[1] : 0;
+              const bool act = nr > 0;
+              double u0, u1, u2, w0, w1, w2;
+              unsigned chain;
+              con_u(sl, act, u0, u1, u2, chain);
+              double jn = env_sum(u0 * acc), j1 = env_sum(u1 * acc), j2 = env_sum(u2 * acc);
+              con_w(u0, u1, u2, chain, w0, w1, w2);
+              if (act) {
+                const double Dc = sl[CG_D], muc = sl[CG_MU], iDc = 1.0 / Dc;
+                const double bnn = sl[CG_B], bn1 = sl[CG_B + 1], bn2 = sl[CG_B + 2], b11 = sl[CG_B + 3], b12 = sl[CG_B + 4],
+                             b22 = sl[CG_B + 5];
+                double dn = 0, d1 = 0, d2 = 0;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                  if (q >= nr) continue;
+                  // row q: J = n + s1 t1 + s2 t2 with (s1, s2) = (mu, 0), (-mu, 0), (0, mu), (0, -mu); condim 1: J = n
+                  const double s1 = nr == 1 ? 0.0 : (q == 0 ? muc : (q == 1 ? -muc : 0.0));
+                  const double s2 = nr == 1 ? 0.0 : (q == 2 ? muc : (q == 3 ? -muc : 0.0));
+                  const double gn = bnn + s1 * bn1 + s2 * bn2, g1 = bn1 + s1 * b11 + s2 * b12, g2 = bn2 + s1 * b12 + s2 * b22;
+                  const double ARii = gn + s1 * g1 + s2 * g2 + iDc;
+                  const double old = sl[CG_F + q];
+                  const double res = (jn + s1 * j1 + s2 * j2) - sl[CG_AREF + q] + old * iDc;
+                  double f = old - res / ARii;
+                  if (f < 0) f = 0;
+                  double delta = f - old, change = 0.5 * delta * delta * ARii + delta * res;
+                  if (change > 1e-10) { f = old; delta = 0; change = 0; }
+                  if (l == 0) { sl[CG_F + q] = f; improvement -= change; }
+                  jn += delta * gn; j1 += delta * g1; j2 += delta * g2;
+                  dn += delta; d1 += delta * s1; d2 += delta * s2;
+                }
+                if (has_dof) acc += dn * w0 + d1 * w1 + d2 * w2;
+              }
+              tp_wave_sync();
+            }
+          }
           iter++;
           if (env_sum(improvement) * scale < m.tolerance) break;
         }
@@ -1655,6 +1790,13 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
         solver_iter = iter;
         frc[0] = fF; frc[1] = fL0; frc[2] = fL1; frc[3] = fE;
         qfrc_constraint = jtf();
+        if constexpr (CON) {
+          if (l < ncon_env)
+#pragma unroll
+            for (int q = 0; q < 4; q++) cfo[q] = myslot[CG_F + q];
+          qfrc_constraint += con_jtf(cfo);
+          if (!has_dof) qfrc_constraint = 0;
+        }
         qacc = qacc_smooth + tp_solve(c, LM.R, LM.dinv, qfrc_constraint);
         if (!has_dof) qacc = 0;
         qacc_ws = qacc;

@@ -933,3 +933,43 @@ def test_rk4_with_cg_and_pgs_tree_parallel(hand_model, solver, monkeypatch):
         s.step(n)
         assert np.abs(res["tp"][0][e] - s.qpos).max() < 1e-8
         assert np.abs(res["tp"][1][e] - s.qvel).max() < 1e-7 * max(1.0, np.abs(s.qvel).max())
+
+
+@pytest.mark.parametrize("plane", [False, True])
+def test_pgs_with_contacts_tree_parallel(hand_model, plane, monkeypatch):
+    """bs_step with solver=PGS and contacts runs k_tpc_pgs (round 1: serial kernels only): contact rows
+    swept in contact order with M^-1 in LDS, against the serial kernels and the oracle (warm starts
+    included: several steps), ragged environment count."""
+    import torch
+    from mujoco_amd import BatchSim, workload
+    from oracle import OracleSim
+    m = workload.with_ground_plane(hand_model, z=-0.05) if plane else hand_model.copy()
+    m.opt_solver = 0
+    E, n = 67, 4
+    q, v = workload.config2_state(m, E, seed=1242)
+    c = workload.config2_ctrl(m, E, seed=1242)
+    res = {}
+    for kern in ("tp", "serial"):
+        monkeypatch.setenv("BS_KERNEL", kern)
+        sim = BatchSim(m, n_envs=E)
+        sim.data.qpos.copy_(torch.as_tensor(q)); sim.data.ctrl.copy_(torch.as_tensor(c))
+        sim.step(1); sim.sync()
+        one = [getattr(sim.data, f).cpu().numpy().copy() for f in ("qacc", "solver_iter", "ncon", "nefc")]
+        sim.step(n - 1); sim.sync()
+        res[kern] = one + [getattr(sim.data, f).cpu().numpy().copy() for f in ("qpos", "qvel", "qacc", "solver_iter", "warning")]
+        del sim
+    monkeypatch.delenv("BS_KERNEL")
+    a, b = res["tp"], res["serial"]
+    assert a[2].sum() > 100 and (a[2] == b[2]).all() and (a[3] == b[3]).all() and (a[8] == 0).all()
+    sc = np.maximum(1.0, np.abs(b[0]).max(axis=1, keepdims=True))
+    assert (np.abs(a[0] - b[0]) / sc).max() < 1e-6            # one step: same sweep, rounding-level differences
+    assert np.abs(a[1].astype(int) - b[1].astype(int)).max() <= 1
+    assert np.abs(a[4] - b[4]).max() < 1e-7 and np.abs(a[5] - b[5]).max() < 1e-5
+    for e in range(0, E, 6):
+        s = OracleSim(m)
+        s.qpos[:] = q[e]; s.ctrl[:] = c[e]
+        s.step(1)
+        assert np.abs(a[0][e] - s.qacc).max() / max(1.0, np.abs(s.qacc).max()) < 1e-6, e
+        assert abs(int(a[1][e]) - s.solver_iter) <= 1 and a[2][e] == s.ncon
+        s.step(n - 1)
+        assert np.abs(a[4][e] - s.qpos).max() < 1e-7 and np.abs(a[5][e] - s.qvel).max() < 1e-5, e
