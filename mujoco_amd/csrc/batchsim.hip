@@ -642,7 +642,7 @@ struct bs_sim {
   TpModel tp;
   bool use_tp = false;
   bool narrow_ws = false, narrow_blocks = false;
-  int nl_grid = 4096;  // wavefronts of the persistent narrowphase (k_c_narrow_list)
+  int nl_grid = 2048;  // wavefronts of the persistent narrowphase (k_c_narrow_list): one resident set at two per SIMD
   bool use_tpc = false;  // contacts: tree-parallel dynamics kernel instead of the serial k_c_dyn (steps only)
   bool contacts = false;
   ColModel cm;
