@@ -1492,55 +1492,96 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
             tp_wave_sync();
           }
           TPC_T(6)
-          // factor: for j = n-1 .. 0  L(j,i) = H(j,i) / sqrt(H(j,j)),  H(i,k) -= L(j,i) L(j,k);
-          // the diagonal keeps 1 / L(j,j)
-          // the update of column jj touches the packed entries q < tri(jj); they are dealt
-          // round-robin to the 32 lanes (entry q = l + 32 t)
-          for (int jj = n - 1; jj >= 0; jj--) {
-            const int tj = jj * (jj + 1) / 2;
-            const tp_lds_d Hj = Hs + tj;
-            double dg = Hj[jj];
-            if (dg < BS_MINVAL) dg = BS_MINVAL;
-            const double inv = 1.0 / sqrt(dg);
-            const double Lji = l < jj ? Hj[l] * inv : 0.0;
-            if (l < jj) Hj[l] = Lji;
-            if (l == jj) Hj[jj] = inv;
+          // factor H = L^T L from the last lane upwards, TWO columns per step (one pair of LDS hand-offs per
+          // panel): for the panel (j1, j0 = j1 - 1) every lane forms the 2x2 block's factor itself from three
+          // broadcast reads, lane l < j0 scales its two entries, and the rank-2 trailing update
+          // H(i,k) -= L(j1,i) L(j1,k) + L(j0,i) L(j0,k) runs over the packed entries q < tri(j0), dealt
+          // round-robin to the 32 lanes (entry q = l + 32 t).  The diagonal keeps 1 / L(j,j).
+          // The forward substitution L^T y = g rides along: g is one more row of the trailing update, every
+          // lane keeps its own entry in a register and publishes it in Gs for the panel that needs it.
+          // row index of packed entry q = l + 32 t, 5 bits each, six per word (a table of ints would be spilled)
+          unsigned ipk[(TPC_NTRI + 5) / 6];
+#pragma unroll
+          for (int w = 0; w < (TPC_NTRI + 5) / 6; w++) ipk[w] = 0;
+#pragma unroll
+          for (int tt = 0; tt < TPC_NTRI; tt++) {
+            const int q = l + tt * TP_LPE;
+            int i = (int)((__fsqrt_rn(8.0f * (float)q + 1.0f) - 1.0f) * 0.5f);
+            if ((i + 1) * (i + 2) / 2 <= q) i++;
+            if (i * (i + 1) / 2 > q) i--;
+            ipk[tt / 6] |= (unsigned)(i & 31) << (5 * (tt % 6));
+          }
+          const tp_lds_d Gs = Us;  // the U staging rows are free again
+          double greg = g, y = 0;
+          Gs[l] = greg;
+          tp_wave_sync();
+          for (int j1 = n - 1; j1 >= 0; j1 -= 2) {
+            const int t1 = j1 * (j1 + 1) / 2, j0 = j1 - 1;
+            const tp_lds_d H1 = Hs + t1;
+            double d1 = H1[j1];
+            if (d1 < BS_MINVAL) d1 = BS_MINVAL;
+            const double inv1 = 1.0 / sqrt(d1);
+            const double y1 = Gs[j1] * inv1;
+            if (j0 < 0) {  // n odd: the last column stands alone and has nothing to update
+              if (l == 0) { H1[0] = inv1; y = y1; }
+              tp_wave_sync();
+              break;
+            }
+            const int tj = t1 - j1;  // tri(j0)
+            const tp_lds_d H0 = Hs + tj;
+            const double l10 = H1[j0] * inv1;
+            double d0 = H0[j0] - l10 * l10;
+            if (d0 < BS_MINVAL) d0 = BS_MINVAL;
+            const double inv0 = 1.0 / sqrt(d0);
+            const double y0 = (Gs[j0] - l10 * y1) * inv0;
+            if (l < j0) {
+              const double a = H1[l] * inv1, b = (H0[l] - l10 * a) * inv0;
+              H1[l] = a; H0[l] = b;
+              greg -= a * y1;
+              greg -= b * y0;
+              Gs[l] = greg;
+            }
+            if (l == j0) { H1[j0] = l10; H0[j0] = inv0; y = y0; }
+            if (l == j1) { H1[j1] = inv1; y = y1; }
             tp_wave_sync();
-            TPC_T(20)
 #pragma unroll
             for (int tt = 0; tt < TPC_NTRI; tt++) {
               if (tt * TP_LPE >= tj) break;
               const int q = l + tt * TP_LPE;
               if (q < tj) {
-                // row / column of packed entry q, recomputed here: a table of them in registers is
-                // spilled, and every spill reload in this loop is a scratch round trip
-                int qq = q;
-                asm volatile("" : "+v"(qq));  // opaque: keeps the compiler from hoisting the table back out of the loops
-                int i = (int)((__fsqrt_rn(8.0f * (float)qq + 1.0f) - 1.0f) * 0.5f);
-                if ((i + 1) * (i + 2) / 2 <= q) i++;
-                if (i * (i + 1) / 2 > q) i--;
-                Hs[q] -= Hj[i] * Hj[q - i * (i + 1) / 2];
+                const int i = (int)((ipk[tt / 6] >> (5 * (tt % 6))) & 31u), k = q - i * (i + 1) / 2;
+                double h = Hs[q];
+                h -= H1[i] * H1[k];
+                h -= H0[i] * H0[k];
+                Hs[q] = h;
               }
             }
             tp_wave_sync();
-            TPC_T(21)
           }
           TPC_T(7)
-          // L^T y = g (descending), then L x = y (ascending)
-          double acc = 0, y = 0;
-          for (int jj = n - 1; jj >= 0; jj--) {
-            const tp_lds_d Hj = Hs + jj * (jj + 1) / 2;
-            const double yl = (g - acc) * Hj[jj];
-            const double yj = bperm(yl, (base + jj) * 4);
-            if (l == jj) y = yj;
-            if (l < jj) acc += Hj[l] * yj;
-          }
-          acc = 0;
-          for (int k = 0; k < n; k++) {
-            const double xl = (y - acc) * Hs[k * (k + 1) / 2 + k];
-            const double xk = bperm(xl, (base + k) * 4);
-            if (l == k) xres = xk;
-            if (l > k && l < n) acc += Hrow[k] * xk;
+          // L x = y (ascending), four unknowns per cross-lane round trip: every lane fetches the four
+          // right-hand sides and resolves the 4x4 triangle itself from broadcast reads of L
+          double acc = 0;
+          for (int k0 = 0; k0 < n; k0 += 4) {
+            const double v = y - acc;
+            double xs[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int jx = 0; jx < 4; jx++) {
+              const int k = k0 + jx;
+              if (k < n) {  // wave-uniform
+                double a = bperm(v, (base + k) * 4);
+                const tp_lds_d Hk = Hs + k * (k + 1) / 2;
+#pragma unroll
+                for (int p2 = 0; p2 < jx; p2++) a -= Hk[k0 + p2] * xs[p2];
+                xs[jx] = a * Hk[k];
+                if (l == k) xres = xs[jx];
+              }
+            }
+            if (l >= k0 + 4 && l < n) {
+#pragma unroll
+              for (int jx = 0; jx < 4; jx++)
+                if (k0 + jx < n) acc += Hrow[k0 + jx] * xs[jx];
+            }
           }
           TPC_T(8)
         }
