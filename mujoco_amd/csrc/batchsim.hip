@@ -730,6 +730,9 @@ static void launch_narrow(bs_sim* s, const DevData& dd, hipStream_t st) {
 // one forward pass (mode 1) or step (mode 0) with contacts through the tree-parallel kernels, for
 // the environments [dd.env0, dd.n_envs) on stream st
 static void launch_tpc_pass(bs_sim* s, const DevData& dd, hipStream_t st, int mode, int dump) {
+#ifdef TPC_CUTS
+  if (const char* e = getenv("BS_CUT")) dump |= (atoi(e) + 1) << 8;
+#endif
   const dim3 g((unsigned)((dd.n_envs - dd.env0 + 1) / 2));
   const size_t lds_col = (size_t)2 * s->cm.ngeom * TPG_SLOT * sizeof(double);
   bs_launch_tp_col(g, lds_col, st, s->dm, s->tp, dd, s->cm, s->cd);

@@ -80,8 +80,10 @@ __global__ __launch_bounds__(NL_THREADS) void k_c_narrow_list(ColModel cm, DevDa
   __shared__ unsigned pre[BS_NSUB + 1];
   __shared__ MprState mpr[NL_THREADS];
   const int tid = threadIdx.x;
-  if (tid < BS_NSUB) {  // first wavefront: inclusive scan of the sub-list lengths
+  const long subcap = col_items_subcap(d.n_envs - d.env0, cm.maxcand);
+  if (tid < BS_NSUB) {  // first wavefront: inclusive scan of the sub-list lengths (never beyond a sub-list's capacity)
     unsigned v = (unsigned)c.stat[BS_STAT_ITEMS + d.range * BS_NSUB + tid];
+    if ((long)v > subcap) v = (unsigned)subcap;
     for (int off = 1; off < BS_NSUB; off <<= 1) {
       const unsigned u = __shfl_up(v, off, 64);
       if (tid >= off) v += u;
@@ -92,7 +94,6 @@ __global__ __launch_bounds__(NL_THREADS) void k_c_narrow_list(ColModel cm, DevDa
   __syncthreads();
   const unsigned total = pre[BS_NSUB];
   const int* items = c.items + col_items_base(d.env0, d.range, cm.maxcand);
-  const long subcap = col_items_subcap(d.n_envs - d.env0, cm.maxcand);
   unsigned acc[2] = {0, 0};
   if constexpr (!PRIM) {
     // every wavefront owns an equal share of the list and its lanes take items from it as they finish

@@ -841,19 +841,37 @@ __device__ __forceinline__ void tp_collide_prep(const DevModel& m, const TpModel
     off = (int)atomicAdd(cd.stat + BS_STAT_ITEMS + d.range * BS_NSUB + sub, (unsigned long long)count);
   off = __builtin_amdgcn_ds_bpermute(base * 4, off);
   if (env_ok) {
-    int* items = cd.items + col_items_base(d.env0, d.range, cm.maxcand) +
-                 (long)sub * col_items_subcap(d.n_envs - d.env0, cm.maxcand) + off;
-    const int tag = (int)(env - d.env0) << 8;
-    for (int k = l; k < count; k += TP_LPE) items[k] = tag | k;
+    // a sub-list holds every candidate of its environments, so the reservation fits whenever the counters
+    // were cleared by the k_tpc pass of the previous step; the test keeps a missed clear (a failed launch)
+    // from writing past the list — the narrowphase clamps the lengths the same way
+    const long subcap = col_items_subcap(d.n_envs - d.env0, cm.maxcand);
+    if (off + count <= subcap) {
+      int* items = cd.items + col_items_base(d.env0, d.range, cm.maxcand) + (long)sub * subcap + off;
+      const int tag = (int)(env - d.env0) << 8;
+      for (int k = l; k < count; k += TP_LPE) items[k] = tag | k;
+    } else if (l == 0) {
+      AT(d.warning, 0) |= 8;
+    }
   }
 }
 
 // developer profiling (-DTPC_PROFILE): wave-clock ticks per section of k_tpc, summed into
 // ColData::stat[8 + section] by lane 0 of every wavefront
-#ifdef TPC_PROFILE
+// -DTPC_CUTS: the kernel returns at section `cut` (bits 8.. of `dump`, BS_CUT in the environment): the time of
+// a section is the difference of two truncated runs, without timers inside the kernel
+#if defined(TPC_PROFILE)
 #define TPC_T(i) { const unsigned long long now_ = clock64(); tacc[i] += now_ - tlast; tlast = now_; }
+#define TPC_TL(i) TPC_T(i)
+#define TPC_C(i)
+#elif defined(TPC_CUTS)
+#define TPC_CLR { if constexpr (CON) { if (blockIdx.x == 0 && cd.stat) cd.stat[BS_STAT_ITEMS + d.range * BS_NSUB + threadIdx.x] = 0; } }
+#define TPC_T(i) { if (cut == i) { TPC_CLR return; } }
+#define TPC_TL(i) { if (cut == i) return 0.0; }
+#define TPC_C(i) TPC_T(i)
 #else
 #define TPC_T(i)
+#define TPC_TL(i)
+#define TPC_C(i)
 #endif
 
 // ------------------------------------------------------------------ kernel body
@@ -872,6 +890,10 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
   int* tbl = sh.tbl;
   const int tid = threadIdx.x;
   constexpr int SL = (CON && PGS) ? TPC_SLOT_PGS : TPC_SLOT;  // contact slot stride
+#ifdef TPC_CUTS
+  const int cut = (dump >> 8) - 1;  // -1: the whole kernel
+  dump &= 255;
+#endif
 #ifdef TPC_PROFILE
   unsigned long long tacc[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = clock64();
 #endif
@@ -1491,7 +1513,7 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
             }
             tp_wave_sync();
           }
-          TPC_T(6)
+          TPC_TL(6)
           // factor H = L^T L from the last lane upwards, TWO columns per step (one pair of LDS hand-offs per
           // panel): for the panel (j1, j0 = j1 - 1) every lane forms the 2x2 block's factor itself from three
           // broadcast reads, lane l < j0 scales its two entries, and the rank-2 trailing update
@@ -1558,7 +1580,7 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
             }
             tp_wave_sync();
           }
-          TPC_T(7)
+          TPC_TL(7)
           // L x = y (ascending), four unknowns per cross-lane round trip: every lane fetches the four
           // right-hand sides and resolves the 4x4 triangle itself from broadcast reads of L
           double acc = 0;
@@ -1583,7 +1605,7 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
                 if (k0 + jx < n) acc += Hrow[k0 + jx] * xs[jx];
             }
           }
-          TPC_T(8)
+          TPC_TL(8)
         }
         return xres;
       };
@@ -1956,6 +1978,9 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
           }
           if constexpr (CON) {
             const double x = con_newton_dir(Hr, s.cj, has_dof ? s.grad : 0.0);
+#ifdef TPC_CUTS
+            if (cut >= 6 && cut <= 8) { TPC_CLR return; }
+#endif
             s.search = has_dof ? -x : 0.0;
           } else {
             const double x = tp_factor_solve(c, Hr, s.grad);
@@ -1964,7 +1989,9 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
           }
           TPC_T(9)
           s.Mv = tp_mul_m(c, Mr, s.search);
+          TPC_C(23)
           residual(s.search, 0.0, s.vf, s.vl0, s.vl1, s.ve, s.cv);
+          TPC_C(24)
           const double alpha = tp_line_search<CON>(m, r, s, gauss, scale, qfrc_smooth);
           if (alpha == 0) break;
           s.qacc += alpha * s.search; s.Ma += alpha * s.Mv;
@@ -1975,6 +2002,7 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
           oldcost = cost;
           TPC_T(10)
         }
+        TPC_C(25)
         solver_iter = iter;
         qacc = s.qacc;
         qacc_ws = s.qacc;
