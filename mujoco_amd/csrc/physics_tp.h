@@ -1521,17 +1521,16 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
           // round-robin to the 32 lanes (entry q = l + 32 t).  The diagonal keeps 1 / L(j,j).
           // The forward substitution L^T y = g rides along: g is one more row of the trailing update, every
           // lane keeps its own entry in a register and publishes it in Gs for the panel that needs it.
-          // row index of packed entry q = l + 32 t, 5 bits each, six per word (a table of ints would be spilled)
-          unsigned ipk[(TPC_NTRI + 5) / 6];
-#pragma unroll
-          for (int w = 0; w < (TPC_NTRI + 5) / 6; w++) ipk[w] = 0;
+          // row index of packed entry q = l + 32 t, 5 bits each (a table of ints would be spilled)
+          unsigned long long pk0 = 0, pk1 = 0;  // chunks 0..11 and 12..
 #pragma unroll
           for (int tt = 0; tt < TPC_NTRI; tt++) {
             const int q = l + tt * TP_LPE;
             int i = (int)((__fsqrt_rn(8.0f * (float)q + 1.0f) - 1.0f) * 0.5f);
             if ((i + 1) * (i + 2) / 2 <= q) i++;
             if (i * (i + 1) / 2 > q) i--;
-            ipk[tt / 6] |= (unsigned)(i & 31) << (5 * (tt % 6));
+            if (tt < 12) pk0 |= (unsigned long long)(i & 31) << (5 * tt);
+            else pk1 |= (unsigned long long)(i & 31) << (5 * (tt - 12));
           }
           const tp_lds_d Gs = Us;  // the U staging rows are free again
           double greg = g, y = 0;
@@ -1566,17 +1565,26 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
             if (l == j0) { H1[j0] = l10; H0[j0] = inv0; y = y0; }
             if (l == j1) { H1[j1] = inv1; y = y1; }
             tp_wave_sync();
+            // two chunks per trip, every LDS read of a trip issued before the first use (lanes beyond the
+            // triangle read entry 0 and do not write).  A rolled loop on purpose: unrolled, the compiler hoists
+            // the sixteen unpacked row indices out of the panel loop and spills them — reloads in here
+#pragma unroll 1
+            for (int tt = 0; tt * TP_LPE < tj; tt += 2) {
+              const unsigned w = (unsigned)(tt < 12 ? pk0 >> (5 * tt) : pk1 >> (5 * (tt - 12)));
+              double h[2], ai[2], ak[2], bi[2], bk[2];
+              int q[2];
 #pragma unroll
-            for (int tt = 0; tt < TPC_NTRI; tt++) {
-              if (tt * TP_LPE >= tj) break;
-              const int q = l + tt * TP_LPE;
-              if (q < tj) {
-                const int i = (int)((ipk[tt / 6] >> (5 * (tt % 6))) & 31u), k = q - i * (i + 1) / 2;
-                double h = Hs[q];
-                h -= H1[i] * H1[k];
-                h -= H0[i] * H0[k];
-                Hs[q] = h;
+              for (int u = 0; u < 2; u++) {
+                q[u] = l + (tt + u) * TP_LPE;
+                const bool on = q[u] < tj;
+                const int i = on ? (int)((w >> (5 * u)) & 31u) : 0;
+                const int k = on ? q[u] - i * (i + 1) / 2 : 0;
+                h[u] = Hs[on ? q[u] : 0];
+                ai[u] = H1[i]; ak[u] = H1[k]; bi[u] = H0[i]; bk[u] = H0[k];
               }
+#pragma unroll
+              for (int u = 0; u < 2; u++)
+                if (q[u] < tj) Hs[q[u]] = (h[u] - ai[u] * ak[u]) - bi[u] * bk[u];
             }
             tp_wave_sync();
           }
