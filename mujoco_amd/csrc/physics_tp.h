@@ -633,9 +633,13 @@ __device__ TP_HELPER_ATTR TpLs tp_ls_eval(TpRows r, TpSol s, double alpha, doubl
   double q0 = 0, q1 = 0, q2 = 0;
   if constexpr (CON) {
 #pragma unroll
+    // one-sided rows without selects on q0 / q1: min(x, 0) contributes the same products when the row is
+    // active and exact zeros when it is not
     for (int q = 0; q < 4; q++) {
       const double x = s.cj[q] + alpha * s.cv[q];
-      if (x < 0) { q0 += 0.5 * r.cD * x * x; q1 += r.cD * x * s.cv[q]; q2 += 0.5 * r.cD * s.cv[q] * s.cv[q]; }
+      const double xm = fmin(x, 0.0);
+      q0 += 0.5 * r.cD * xm * xm; q1 += r.cD * xm * s.cv[q];
+      if (x < 0) q2 += 0.5 * r.cD * s.cv[q] * s.cv[q];
     }
   }
   if (r.own) {
@@ -649,12 +653,14 @@ __device__ TP_HELPER_ATTR TpLs tp_ls_eval(TpRows r, TpSol s, double alpha, doubl
     else { q0 += 0.5 * r.Df * x * x; q1 += r.Df * x * s.vf; q2 += 0.5 * r.Df * s.vf * s.vf; }
   }
   {
-    const double x = s.jl0 + alpha * s.vl0;
-    if (x < 0) { q0 += 0.5 * r.Dl0 * x * x; q1 += r.Dl0 * x * s.vl0; q2 += 0.5 * r.Dl0 * s.vl0 * s.vl0; }
+    const double x = s.jl0 + alpha * s.vl0, xm = fmin(x, 0.0);
+    q0 += 0.5 * r.Dl0 * xm * xm; q1 += r.Dl0 * xm * s.vl0;
+    if (x < 0) q2 += 0.5 * r.Dl0 * s.vl0 * s.vl0;
   }
   {
-    const double x = s.jl1 + alpha * s.vl1;
-    if (x < 0) { q0 += 0.5 * r.Dl1 * x * x; q1 += r.Dl1 * x * s.vl1; q2 += 0.5 * r.Dl1 * s.vl1 * s.vl1; }
+    const double x = s.jl1 + alpha * s.vl1, xm = fmin(x, 0.0);
+    q0 += 0.5 * r.Dl1 * xm * xm; q1 += r.Dl1 * xm * s.vl1;
+    if (x < 0) q2 += 0.5 * r.Dl1 * s.vl1 * s.vl1;
   }
   q0 = env_sum(q0); q1 = env_sum(q1); q2 = env_sum(q2);
   TpLs p;
@@ -1505,10 +1511,16 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
               const double v0 = Cnn * u0 + Cn1 * u1 + Cn2 * u2;
               const double v1 = Cn1 * u0 + C11 * u1;
               const double v2 = Cn2 * u0 + C22 * u2;
-              while (chain) {
-                const int k = __builtin_ctz(chain);
+              while (chain) {  // two entries per trip: their eight LDS reads are in flight together
+                const int k0 = __builtin_ctz(chain);
                 chain &= chain - 1;
-                Hrow[k] += v0 * Us[3 * k] + v1 * Us[3 * k + 1] + v2 * Us[3 * k + 2];
+                const bool two = chain != 0;
+                const int k1 = two ? __builtin_ctz(chain) : k0;
+                chain &= chain - 1;
+                const double a0 = Us[3 * k0], a1 = Us[3 * k0 + 1], a2 = Us[3 * k0 + 2], h0 = Hrow[k0];
+                const double b0 = Us[3 * k1], b1 = Us[3 * k1 + 1], b2 = Us[3 * k1 + 2], h1 = Hrow[k1];
+                Hrow[k0] = h0 + (v0 * a0 + v1 * a1 + v2 * a2);
+                if (two) Hrow[k1] = h1 + (v0 * b0 + v1 * b1 + v2 * b2);
               }
             }
             tp_wave_sync();
