@@ -517,6 +517,37 @@ static int model_image(bs_model* m, int device, const DeviceImage** out) {
   PUT_CD(geom_rbound, s.geom_rbound, ng); PUT_CD(geom_margin, s.geom_margin, ng); PUT_CD(geom_gap, s.geom_gap, ng);
   PUT_CD(geom_friction, s.geom_friction, ng * 3); PUT_CD(geom_solref, s.geom_solref, ng * 2);
   PUT_CD(geom_solimp, s.geom_solimp, ng * 5); PUT_CD(geom_solmix, s.geom_solmix, ng);
+  // per-pair contact-row constants: the arithmetic of physics_contact.h::make_contact_rows that does not depend
+  // on the state (parameter mixing, mj_makeImpedance's K / B, diagApprox, the pyramid's R scale)
+  std::vector<double> pcon((size_t)(s.npair > 0 ? s.npair : 1) * BS_PAIR_CON, 0.0);
+  std::vector<int32_t> pbody((size_t)(s.npair > 0 ? s.npair : 1) * 2, 0);
+  for (int p = 0; p < s.npair; p++) {
+    const int g1 = s.pair_geom1[p], g2 = s.pair_geom2[p];
+    const int b1 = s.geom_bodyid[g1], b2 = s.geom_bodyid[g2];
+    double* r = &pcon[(size_t)p * BS_PAIR_CON];
+    const int dim = s.geom_condim[g1] > s.geom_condim[g2] ? s.geom_condim[g1] : s.geom_condim[g2];
+    const double mu = fmax(s.geom_friction[3 * g1], s.geom_friction[3 * g2]);
+    const double s1 = s.geom_solmix[g1], s2 = s.geom_solmix[g2];
+    double mix;
+    if (s1 >= BS_MINVAL && s2 >= BS_MINVAL) mix = s1 / (s1 + s2);
+    else if (s1 < BS_MINVAL && s2 < BS_MINVAL) mix = 0.5;
+    else mix = s1 < BS_MINVAL ? 0.0 : 1.0;
+    double solref[2], solimp[5];
+    for (int q = 0; q < 2; q++) solref[q] = mix * s.geom_solref[2 * g1 + q] + (1 - mix) * s.geom_solref[2 * g2 + q];
+    for (int q = 0; q < 5; q++) solimp[q] = mix * s.geom_solimp[5 * g1 + q] + (1 - mix) * s.geom_solimp[5 * g2 + q];
+    double K, B;
+    kb_from_solref(dm, solref, solimp, K, B);
+    const double tran = s.body_invweight0[2 * b1] + s.body_invweight0[2 * b2];
+    const double mue = mu / sqrt(fmax(BS_MINVAL, s.impratio));
+    r[0] = fmax(s.geom_margin[g1], s.geom_margin[g2]) - fmax(s.geom_gap[g1], s.geom_gap[g2]);
+    r[1] = mu; r[2] = K; r[3] = B;
+    for (int q = 0; q < 5; q++) r[4 + q] = solimp[q];
+    r[9] = dim == 1 ? tran : tran + mu * mu * tran;
+    r[10] = 2 * mue * mue;
+    pbody[2 * p] = b1 | (dim << 16); pbody[2 * p + 1] = b2;
+  }
+  PUT_CD(pair_con, pcon.data(), pcon.size());
+  PUT_CI(pair_body, pbody.data(), pbody.size());
   PUT_CD(hull_vert, s.hull_vert, s.nhullvert * 3);
   PUT_CI(mesh_vertadr, s.mesh_vertadr, s.nmesh);
   PUT_CI(hull_adj_start, s.hull_adj_start, s.nhullvert > 0 ? s.nhullvert + 1 : 0);

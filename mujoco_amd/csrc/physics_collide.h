@@ -29,6 +29,7 @@ __host__ __device__ inline bool pair_supported_types(int t1, int t2) {  // t1 <=
   return t1 != BS_GEOM_HFIELD && t2 != BS_GEOM_HFIELD && t2 != BS_GEOM_PLANE;
 }
 
+#define BS_PAIR_CON 12
 struct ColModel {
   int npair, ngeom, maxcand, maxcon, mpr_iterations;
   double mpr_tolerance;
@@ -48,6 +49,10 @@ struct ColModel {
   const double *geom_obb; // [ngeom][6] box around the hull in the geom frame: centre, half extents (< 0: none)
   const double *geom_size; // [ngeom][3] mjModel.geom_size (primitives)
   const int *pair_nsub;    // [npair] sub-contacts a pair can produce (0: pair of unsupported geom types)
+  // state-independent part of a pair's contact rows (host, model_image; k_tpc reads one record instead of three
+  // dependent levels of per-geom loads): {margin - gap, mu, K, B, mixed solimp[5], diagApprox, 2 mu_e^2 (dim > 1), -}
+  const double *pair_con;  // [npair][BS_PAIR_CON]
+  const int *pair_body;    // [npair][2]: body of geom1 | condim << 16, body of geom2
   int nl_min_share;        // least number of work-list items a wavefront of k_c_narrow_list takes
   int has_prim;            // some pair involves a primitive geom: the narrowphase kernels' PRIM instantiation runs
 };

@@ -1302,37 +1302,20 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
         V3 cpos = {0, 0, 0};
         if (l < count && con_on) {
           const int pr = ((tp_lds_i)(myslot + CG_PAIR))[0];
-          const int g1 = cm.pair_geom1[pr], g2 = cm.pair_geom2[pr];
-          const int b1 = cm.geom_bodyid[g1], b2 = cm.geom_bodyid[g2];
+          const int bb = cm.pair_body[2 * pr], b2 = cm.pair_body[2 * pr + 1];
+          const int b1 = bb & 0xffff, dim = bb >> 16;
+          const double* pc = cm.pair_con + (size_t)BS_PAIR_CON * pr;  // the pair's state-independent row constants
           b1_sa = (base + b1) * 4; b2_sa = (base + b2) * 4;
           ((tp_lds_i)(myslot + CG_MASK))[0] = tbl[TPL_ANCMASK * 64 + base + b1];
           ((tp_lds_i)(myslot + CG_MASK))[1] = tbl[TPL_ANCMASK * 64 + base + b2];
           cpos = {myslot[CG_POS], myslot[CG_POS + 1], myslot[CG_POS + 2]};
-          const double margin = fmax(cm.geom_margin[g1], cm.geom_margin[g2]) - fmax(cm.geom_gap[g1], cm.geom_gap[g2]);
+          const double margin = pc[0];
           const double dist = myslot[CG_DIST];
           if (dist < margin) {
-            const int dim = cm.geom_condim[g1] > cm.geom_condim[g2] ? cm.geom_condim[g1] : cm.geom_condim[g2];
-            const double mu = fmax(cm.geom_friction[3 * g1], cm.geom_friction[3 * g2]);
-            const double s1 = cm.geom_solmix[g1], s2 = cm.geom_solmix[g2];
-            double mix;
-            if (s1 >= BS_MINVAL && s2 >= BS_MINVAL) mix = s1 / (s1 + s2);
-            else if (s1 < BS_MINVAL && s2 < BS_MINVAL) mix = 0.5;
-            else mix = s1 < BS_MINVAL ? 0.0 : 1.0;
-            double solref[2], solimp[5];
-#pragma unroll
-            for (int q = 0; q < 2; q++) solref[q] = mix * cm.geom_solref[2 * g1 + q] + (1 - mix) * cm.geom_solref[2 * g2 + q];
-#pragma unroll
-            for (int q = 0; q < 5; q++) solimp[q] = mix * cm.geom_solimp[5 * g1 + q] + (1 - mix) * cm.geom_solimp[5 * g2 + q];
-            double K, B;
-            const double imp = tp_impedance(solimp, dist, margin);
-            kb_from_solref(m, solref, solimp, K, B);
-            const double tran = m.body_invweight0[2 * b1] + m.body_invweight0[2 * b2];
-            const double diag = dim == 1 ? tran : tran + mu * mu * tran;
-            double R = fmax(BS_MINVAL, (1 - imp) * diag / imp);
-            if (dim > 1) {
-              const double mue = mu / sqrt(fmax(BS_MINVAL, m.impratio));
-              R = fmax(BS_MINVAL, 2 * mue * mue * R);
-            }
+            const double mu = pc[1], K = pc[2], B = pc[3];
+            const double imp = tp_impedance(pc + 4, dist, margin);
+            double R = fmax(BS_MINVAL, (1 - imp) * pc[9] / imp);
+            if (dim > 1) R = fmax(BS_MINVAL, pc[10] * R);
             cnr = dim == 1 ? 1 : 4; cmu = dim == 1 ? 0.0 : mu; cDrow = 1.0 / R;
             myslot[CG_D] = cDrow; myslot[CG_MU] = cmu;
             cB = B; ckimp = K * imp * (dist - margin);
