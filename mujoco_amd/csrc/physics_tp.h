@@ -2064,17 +2064,20 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
         // ---- A12 Euler with implicit joint damping
         double acc = qacc;
         if (m.damped) {
-          TpFac LE;
+          const double rhs = has_dof ? qfrc_smooth + qfrc_constraint : 0.0;
           if (euler_early) {  // own lane's values: no synchronisation needed
+            TpFac LE;
 #pragma unroll
             for (int a = 0; a < TP_MAXD; a++) LE.R.r[a] = sh.park[a * 64 + tid];
             LE.dinv = sh.park[TP_MAXD * 64 + tid];
+            acc = tp_solve(c, LE.R, LE.dinv, rhs);
           } else {
+            // no early factor (k_tpc has no LDS to park it in): the forward substitution rides in the
+            // factorisation's leaves-to-root exchanges, as in Newton's direction
             TpRow Hr = Mr;
             Hr.r[0] += h * damping;
-            LE = tp_factor(c, Hr);
+            acc = tp_factor_solve(c, Hr, rhs);
           }
-          acc = tp_solve(c, LE.R, LE.dinv, has_dof ? qfrc_smooth + qfrc_constraint : 0.0);
         }
         qvel += h * acc;
         qpos += h * qvel;
