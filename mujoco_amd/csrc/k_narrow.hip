@@ -76,10 +76,14 @@ __global__ __launch_bounds__(NW_THREADS) void k_c_narrow_ws(ColModel cm, DevData
 // narrowphase over the work list k_tp_col wrote: one lane per item whatever environment it belongs
 // to, so every wavefront but the last is full
 template <bool PRIM>
-__global__ __launch_bounds__(NL_THREADS) void k_c_narrow_list(ColModel cm, DevData d, ColData c) {
+__global__ __launch_bounds__(NL_THREADS, NL_OCC) void k_c_narrow_list(ColModel cm, DevData d, ColData c) {
   __shared__ unsigned pre[BS_NSUB + 1];
   __shared__ MprState mpr[NL_THREADS];
   const int tid = threadIdx.x;
+#ifdef NL_PAD
+  __shared__ int padd[NL_PAD];
+  if (c.stat == nullptr && d.n_envs < 0) padd[tid] = 1;
+#endif
   const long subcap = col_items_subcap(d.n_envs - d.env0, cm.maxcand);
   if (tid < BS_NSUB) {  // first wavefront: inclusive scan of the sub-list lengths (never beyond a sub-list's capacity)
     unsigned v = (unsigned)c.stat[BS_STAT_ITEMS + d.range * BS_NSUB + tid];

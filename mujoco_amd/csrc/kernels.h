@@ -13,6 +13,9 @@
 #define NB_THREADS 128
 #define NW_THREADS 128
 #define NL_THREADS 64  // one wavefront per block measured best (3.21 / 3.25 / 3.30 ms per step for 64 / 128 / 256)
+#ifndef NL_OCC
+#define NL_OCC 2        // wavefronts per SIMD k_c_narrow_list is compiled for (register budget 512 / NL_OCC)
+#endif
 #ifndef NL_MIN_SHARE
 #define NL_MIN_SHARE 192  // least number of work-list items a wavefront of k_c_narrow_list takes
 #endif

@@ -149,7 +149,10 @@ struct CObj {
   M3 R;
   double margin;
 };
-struct Spt { V3 v, v1, v2; };
+struct Spt { V3 v, v1, v2; };  // support point of the Minkowski difference as the support calls return it
+// ... and as the MPR state keeps it: v2 = v1 - v is rebuilt where the contact position needs it (one rounding of
+// a coordinate-sized number away from the stored v2: 1e-17 m), a third less LDS per lane
+struct SptS { V3 v, v1; };
 
 #ifdef NP_PROFILE
 __device__ unsigned long long np_hist_climb[32], np_hist_sup[64];
@@ -278,15 +281,15 @@ __device__ inline Spt md_support(CObj& a, CObj& b, const V3& dir, bool only_b = 
   s.v = sub(s.v1, s.v2);
   return s;
 }
-__device__ __forceinline__ V3 portal_dir(const Spt* P) {
+__device__ __forceinline__ V3 portal_dir(const SptS* P) {
   return normalized(cross(sub(P[2].v, P[1].v), sub(P[3].v, P[1].v)));
 }
-__device__ __forceinline__ bool reach_tol(const Spt* P, const Spt& v4, const V3& dir, double tol) {
+__device__ __forceinline__ bool reach_tol(const SptS* P, const SptS& v4, const V3& dir, double tol) {
   const double dv4 = dot(v4.v, dir);
   const double m = fmin(fmin(dv4 - dot(P[1].v, dir), dv4 - dot(P[2].v, dir)), dv4 - dot(P[3].v, dir));
   return c_is_eq(m, tol) || m < tol;
 }
-__device__ __forceinline__ void expand_portal(Spt* P, const V3& p0, const Spt& v4) {
+__device__ __forceinline__ void expand_portal(SptS* P, const V3& p0, const SptS& v4) {
   const V3 v4v0 = cross(v4.v, p0);
   if (dot(P[1].v, v4v0) > 0) {
     if (dot(P[2].v, v4v0) > 0) P[1] = v4;
@@ -338,30 +341,29 @@ __device__ __forceinline__ void swap3(V3& a, V3& b) {
   a.x = b.x; a.y = b.y; a.z = b.z;
   b.x = x; b.y = y; b.z = z;
 }
-__device__ __forceinline__ void swap_spt(Spt& a, Spt& b) { swap3(a.v, b.v); swap3(a.v1, b.v1); swap3(a.v2, b.v2); }
+__device__ __forceinline__ void swap_spt(SptS& a, SptS& b) { swap3(a.v, b.v); swap3(a.v1, b.v1); }
 struct MprState {
   V3 p0;     // portal point 0 = centre difference (its two support points are the geom centres)
-  Spt P[3];  // portal points 1..3
+  SptS P[3]; // portal points 1..3
   V3 d;           // direction of the next support query
-  int state, guard, it;
+  int pk;         // state (bits 0-2) | guard (3-10) | it (11-): one word, so a lane's slot is 200 bytes
 };
 __device__ __forceinline__ void mpr_begin(MprState& M, const V3& c1, const V3& c2) {
   const V3 origin = {0, 0, 0};
   M.p0 = sub(c1, c2);
   if (v_eq(M.p0, origin)) M.p0 = {BS_CCD_EPS * 10, 0, 0};
   M.d = normalized(neg(M.p0));
-  M.state = 0; M.guard = 0; M.it = 0;
+  M.pk = 0;
 }
 // consumes the support point `s` of direction M.d; returns 0 = query M.d again, 1 = the inflated
 // hulls intersect (depth, dir = unit normal obj1 -> obj2, pos filled), 2 = they do not
-__device__ __forceinline__ int mpr_step(MprState& M, const Spt& s, const V3& c1, const V3& c2, double tol, int maxit,
+__device__ __forceinline__ int mpr_step(MprState& M, const Spt& sfull, const V3& c1, const V3& c2, double tol, int maxit,
                                         double& depth, V3& dir, V3& pos, int& iters) {
-  Spt* P = M.P - 1;  // P[1..3]
+  SptS* P = M.P - 1;  // P[1..3]
+  const SptS s = {sfull.v, sfull.v1};
   const V3& p0 = M.p0;
   V3& d = M.d;
-  int& state = M.state;
-  int& guard = M.guard;
-  int& it = M.it;
+  int state = M.pk & 7, guard = (M.pk >> 3) & 255, it = M.pk >> 11;
   const V3 origin = {0, 0, 0};
   bool check_refine = false;
   if (state == 0) {
@@ -370,7 +372,7 @@ __device__ __forceinline__ int mpr_step(MprState& M, const Spt& s, const V3& c1,
     if (c_is_zero(dt) || dt < 0) return 2;
     d = cross(p0, P[1].v);
     if (c_is_zero(dot(d, d))) {
-      pos = {0.5 * (P[1].v1.x + P[1].v2.x), 0.5 * (P[1].v1.y + P[1].v2.y), 0.5 * (P[1].v1.z + P[1].v2.z)};
+      pos = {0.5 * (sfull.v1.x + sfull.v2.x), 0.5 * (sfull.v1.y + sfull.v2.y), 0.5 * (sfull.v1.z + sfull.v2.z)};
       if (v_eq(P[1].v, origin)) { depth = 0; dir = origin; return 1; }  // touching
       depth = sqrt(dot(P[1].v, P[1].v));
       dir = normalized(P[1].v);
@@ -439,7 +441,7 @@ __device__ __forceinline__ int mpr_step(MprState& M, const Spt& s, const V3& c1,
 #pragma unroll
       for (int i = 1; i < 4; i++) {
         p1.x += bb[i] * P[i].v1.x; p1.y += bb[i] * P[i].v1.y; p1.z += bb[i] * P[i].v1.z;
-        p2.x += bb[i] * P[i].v2.x; p2.y += bb[i] * P[i].v2.y; p2.z += bb[i] * P[i].v2.z;
+        p2.x += bb[i] * (P[i].v1.x - P[i].v.x); p2.y += bb[i] * (P[i].v1.y - P[i].v.y); p2.z += bb[i] * (P[i].v1.z - P[i].v.z);
       }
       pos = {0.5 * (p1.x * inv + p2.x * inv), 0.5 * (p1.y * inv + p2.y * inv), 0.5 * (p1.z * inv + p2.z * inv)};
       return 1;
@@ -456,6 +458,7 @@ __device__ __forceinline__ int mpr_step(MprState& M, const Spt& s, const V3& c1,
     if (c_is_zero(x) || x > 0) { it = 0; state = 4; }  // portal encloses the origin ray
     else state = 3;
   }
+  M.pk = state | (guard << 3) | (it << 11);
   return 0;
 }
 // returns true when the inflated hulls intersect; fills depth, dir (unit, obj1 -> obj2), pos
