@@ -144,6 +144,8 @@ struct CObj {
   // every record is {x, y, z, id | degree << 20 | first adjacency entry << 32}, so a climb step is
   // one dependent load (the neighbours of the vertex just chosen), not two
   const double4 *vert4, *nbr4, *start4;
+  const double4 *vert_all, *start_all;  // the whole tables (uniform) and this mesh's first record in them:
+  int vbase, sbase;                     // md_support addresses records with 32-bit offsets from a uniform base
   int cache;
   V3 xpos;
   M3 R;
@@ -205,6 +207,11 @@ __device__ inline V3 hull_support(CObj& o, const V3& dir) {
 // sum of the two climbs among its lanes, not for the longest climb on each hull
 // only_b (per lane; plane items of the persistent narrowphase): hull 1 is not climbed — the lane enters
 // the loop in its second phase — and the result's v2 is what hull_support(b, -dir) returns
+// record `idx` of a table with a 32-bit byte offset: base (uniform) + zero-extended offset is one address
+// operand of the load, where 64-bit index arithmetic costs four VALU instructions per record
+__device__ __forceinline__ double4 ld_rec32(const double4* base, int idx) {
+  return *(const double4*)((const char*)base + ((unsigned)idx << 5));
+}
 __device__ inline Spt md_support(CObj& a, CObj& b, const V3& dir, bool only_b = false) {
   const V3 da = {a.R.a[0] * dir.x + a.R.a[3] * dir.y + a.R.a[6] * dir.z, a.R.a[1] * dir.x + a.R.a[4] * dir.y + a.R.a[7] * dir.z,
                  a.R.a[2] * dir.x + a.R.a[5] * dir.y + a.R.a[8] * dir.z};
@@ -212,8 +219,8 @@ __device__ inline Spt md_support(CObj& a, CObj& b, const V3& dir, bool only_b = 
   const V3 db = {b.R.a[0] * nd.x + b.R.a[3] * nd.y + b.R.a[6] * nd.z, b.R.a[1] * nd.x + b.R.a[4] * nd.y + b.R.a[7] * nd.z,
                  b.R.a[2] * nd.x + b.R.a[5] * nd.y + b.R.a[8] * nd.z};
   // starts of both climbs: better of (previous support vertex, table vertex of the direction bin)
-  const double4 ca = a.vert4[a.cache], ta = a.start4[dir_bin(da.x, da.y, da.z)];
-  const double4 cb = b.vert4[b.cache], tb = b.start4[dir_bin(db.x, db.y, db.z)];
+  const double4 ca = ld_rec32(a.vert_all, a.vbase + a.cache), ta = ld_rec32(a.start_all, a.sbase + dir_bin(da.x, da.y, da.z));
+  const double4 cb = ld_rec32(b.vert_all, b.vbase + b.cache), tb = ld_rec32(b.start_all, b.sbase + dir_bin(db.x, db.y, db.z));
   V3 best = {ca.x, ca.y, ca.z};
   double vmax = best.x * da.x + best.y * da.y + best.z * da.z, rec = ca.w;
   {
@@ -239,11 +246,11 @@ __device__ inline Spt md_support(CObj& a, CObj& b, const V3& dir, bool only_b = 
     // the four-at-a-time loop: bitwise the same climb).
     double4 p[MD_BATCH];
 #pragma unroll
-    for (int q = 0; q < 4; q++) p[q] = nbr[k + q < k1 ? k + q : k1 - 1];
+    for (int q = 0; q < 4; q++) p[q] = ld_rec32(nbr, k + q < k1 ? k + q : k1 - 1);
     const bool more = k + 4 < k1;
     if (more) {
 #pragma unroll
-      for (int q = 4; q < MD_BATCH; q++) p[q] = nbr[k + q < k1 ? k + q : k1 - 1];
+      for (int q = 4; q < MD_BATCH; q++) p[q] = ld_rec32(nbr, k + q < k1 ? k + q : k1 - 1);
     }
 #pragma unroll
     for (int q = 0; q < 4; q++) {
@@ -683,6 +690,7 @@ __device__ inline void col_narrowphase(const ColModel& cm, const DevData& d, con
     o.vert4 = cm.hull_vert4 + cm.mesh_vertadr[mesh];
     o.nbr4 = cm.hull_nbr4; o.cache = 0;
     o.start4 = cm.hull_start4 + (size_t)mesh * BS_NSTART;
+    o.vert_all = cm.hull_vert4; o.start_all = cm.hull_start4; o.vbase = cm.mesh_vertadr[mesh]; o.sbase = mesh * BS_NSTART;
     o.xpos = {AT(c.geom_xpos, 3 * g), AT(c.geom_xpos, 3 * g + 1), AT(c.geom_xpos, 3 * g + 2)};
     for (int k = 0; k < 9; k++) o.R.a[k] = AT(c.geom_xmat, 9 * g + k);
     o.margin = 0;
@@ -791,6 +799,8 @@ __device__ inline void col_narrow_persistent(const ColModel& cm, const DevData& 
   CObj a, b;
   a.type = b.type = BS_GEOM_MESH; a.size = b.size = {0, 0, 0};
   a.vert4 = b.vert4 = cm.hull_vert4; a.nbr4 = b.nbr4 = cm.hull_nbr4; a.start4 = b.start4 = cm.hull_start4;
+  a.vert_all = b.vert_all = cm.hull_vert4; a.start_all = b.start_all = cm.hull_start4;
+  a.vbase = b.vbase = 0; a.sbase = b.sbase = 0;
   a.cache = b.cache = 0; a.margin = b.margin = 0;
   a.xpos = b.xpos = {0, 0, 0};
   for (int k = 0; k < 9; k++) { a.R.a[k] = 0; b.R.a[k] = 0; }
@@ -813,8 +823,7 @@ __device__ inline void col_narrow_persistent(const ColModel& cm, const DevData& 
         const int g1 = cm.pair_geom1[p], g2 = cm.pair_geom2[p];
         margin = fmax(cm.geom_margin[g1], cm.geom_margin[g2]);
         const int mb = cm.geom_dataid[g2];
-        b.vert4 = cm.hull_vert4 + cm.mesh_vertadr[mb];
-        b.start4 = cm.hull_start4 + (size_t)mb * BS_NSTART;
+        b.vbase = cm.mesh_vertadr[mb]; b.sbase = mb * BS_NSTART;
         b.cache = 0;
         b.xpos = {AT(c.geom_xpos, 3 * g2), AT(c.geom_xpos, 3 * g2 + 1), AT(c.geom_xpos, 3 * g2 + 2)};
         for (int k = 0; k < 9; k++) b.R.a[k] = AT(c.geom_xmat, 9 * g2 + k);
@@ -825,12 +834,11 @@ __device__ inline void col_narrow_persistent(const ColModel& cm, const DevData& 
           pp = {AT(c.geom_xpos, 3 * g1), AT(c.geom_xpos, 3 * g1 + 1), AT(c.geom_xpos, 3 * g1 + 2)};
           b.margin = 0;
           // the partner is not climbed (md_support's only_b): it points at the same hull so its start loads are valid
-          a.vert4 = b.vert4; a.start4 = b.start4; a.cache = 0; a.margin = 0;
+          a.vbase = b.vbase; a.sbase = b.sbase; a.cache = 0; a.margin = 0;
           M.d = pn;  // the hull is queried along -d
         } else {
           const int ma = cm.geom_dataid[g1];
-          a.vert4 = cm.hull_vert4 + cm.mesh_vertadr[ma];
-          a.start4 = cm.hull_start4 + (size_t)ma * BS_NSTART;
+          a.vbase = cm.mesh_vertadr[ma]; a.sbase = ma * BS_NSTART;
           a.cache = 0;
           a.xpos = {AT(c.geom_xpos, 3 * g1), AT(c.geom_xpos, 3 * g1 + 1), AT(c.geom_xpos, 3 * g1 + 2)};
           for (int k = 0; k < 9; k++) a.R.a[k] = AT(c.geom_xmat, 9 * g1 + k);
