@@ -74,6 +74,7 @@ struct bs_model {
   std::string tp_why;
   std::vector<int32_t> tp_table;  // [TPI_TOTAL][32]
   std::vector<double> tp_dtable;  // [TPD_TOTAL][32]
+  std::vector<double> tp_ktable;  // [32][TPK_N]
   std::vector<int32_t> tp_pgs;    // PGS sweep order (TpModel::pgs_order)
   TpModel tp;
   std::vector<DeviceImage> images;
@@ -205,6 +206,29 @@ static void build_tp(bs_model* m) {
       kb_from_solref(hm, m->eq_solref.data() + 2 * r, m->eq_solimp.data() + 5 * r, K, B);
       dat(TPD_EQ_K, b) = K; dat(TPD_EQ_B, b) = B;
       dat(TPD_EQ_DIAG, b) = iw + s.dof_invweight0[m->eq_dof2[r]];
+    }
+  }
+  // the lane-major record of everything a lane reads per step (TPK_*)
+  std::vector<double>& Kt = m->tp_ktable;
+  Kt.assign((size_t)TP_LPE * TPK_N, 0.0);
+  for (int l = 0; l < TP_LPE; l++) {
+    double* r = &Kt[(size_t)l * TPK_N];
+    const int b = l < nb ? l : 0;  // lanes beyond the bodies read body 0, lanes without a joint read joint 0 (as the kernels index)
+    const int j = l < nb ? jnt_of[b] : -1;
+    for (int q = 0; q < 3; q++) { r[TPK_BPOS + q] = s.body_pos[3 * b + q]; r[TPK_IPOS + q] = s.body_ipos[3 * b + q]; r[TPK_INERTIA + q] = s.body_inertia[3 * b + q]; }
+    for (int q = 0; q < 4; q++) { r[TPK_BQUAT + q] = s.body_quat[4 * b + q]; r[TPK_IQUAT + q] = s.body_iquat[4 * b + q]; }
+    for (int f = 0; f < TPD_TOTAL; f++) r[TPK_D0 + f] = dat(f, l);
+    const int jj = j >= 0 ? j : 0;
+    if (s.njnt > 0) {
+      for (int q = 0; q < 3; q++) { r[TPK_JPOS + q] = s.jnt_pos[3 * jj + q]; r[TPK_JAX + q] = s.jnt_axis[3 * jj + q]; }
+      r[TPK_ARMATURE] = s.dof_armature[jj];
+      r[TPK_JMARGIN] = s.jnt_margin[jj]; r[TPK_JRANGE] = s.jnt_range[2 * jj]; r[TPK_JRANGE + 1] = s.jnt_range[2 * jj + 1];
+      for (int q = 0; q < 5; q++) r[TPK_JSOLIMP + q] = s.jnt_solimp[5 * jj + q];
+    }
+    const int e = at(TPI_EQ_OWN, l);
+    if (e >= 0) {
+      for (int q = 0; q < 5; q++) { r[TPK_EQDATA + q] = m->eq_data[5 * e + q]; r[TPK_EQSOLIMP + q] = m->eq_solimp[5 * e + q]; }
+      r[TPK_EQQPOS0] = s.qpos0[m->eq_jnt2[e]];
     }
   }
   // PGS sweep order = efc order: equalities (owner lanes listed here), then frictionloss rows and limits in
@@ -634,11 +658,12 @@ static int model_image(bs_model* m, int device, const DeviceImage** out) {
 #undef PUT_CI
 #undef PUT_CD
   TpModel tp = m->tp;
-  tp.lane = nullptr; tp.lane_d = nullptr; tp.pgs_order = nullptr;
+  tp.lane = nullptr; tp.lane_d = nullptr; tp.lane_k = nullptr; tp.pgs_order = nullptr;
   if (m->tp_ok) {
     fix.push_back({pk.add(m->tp_pgs.data(), m->tp_pgs.size() * sizeof(int32_t)), (void**)&tp.pgs_order});
     fix.push_back({pk.add(m->tp_table.data(), m->tp_table.size() * sizeof(int32_t)), (void**)&tp.lane});
     fix.push_back({pk.add(m->tp_dtable.data(), m->tp_dtable.size() * sizeof(double)), (void**)&tp.lane_d});
+    fix.push_back({pk.add(m->tp_ktable.data(), m->tp_ktable.size() * sizeof(double)), (void**)&tp.lane_k});
   }
 #undef PUT_I
 #undef PUT_D

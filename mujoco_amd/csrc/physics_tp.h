@@ -55,10 +55,22 @@ enum {
   TPD_ACT_CLO, TPD_ACT_CHI, TPD_ACT_FLO, TPD_ACT_FHI,
   TPD_TOTAL
 };
+// ... and every model constant a lane reads per step, as ONE record per lane, [32][TPK_N] (lane-major):
+// a single per-lane base address plus immediate offsets.  (Separate arrays cost one hoisted 64-bit address
+// each; the compiler kept 33 of them in scratch and reloaded them every step.)
+enum {
+  TPK_BPOS = 0, TPK_BQUAT = 3, TPK_JPOS = 7, TPK_JAX = 10, TPK_IPOS = 13, TPK_IQUAT = 16, TPK_INERTIA = 20,
+  TPK_ARMATURE = 23,
+  TPK_D0 = 24,                          // + TPD_* field
+  TPK_JMARGIN = TPK_D0 + TPD_TOTAL, TPK_JRANGE, TPK_JSOLIMP = TPK_JRANGE + 2,
+  TPK_EQDATA = TPK_JSOLIMP + 5, TPK_EQSOLIMP = TPK_EQDATA + 5, TPK_EQQPOS0 = TPK_EQSOLIMP + 5,  // of the equality the lane owns; qpos0 of its other joint
+  TPK_N = (TPK_EQQPOS0 + 2) & ~1
+};
 
 struct TpModel {
   const int* lane;  // [TPI_TOTAL][32]
   const double* lane_d;  // [TPD_TOTAL][32]
+  const double* lane_k;  // [32][TPK_N]
   int maxdepth, maxdd, nroots;
   int jump_rounds;  // ceil(log2(maxdepth)): pointer-jumping rounds that reach the world from every body
   int fold_minlvl;  // leaves-to-root folds (crb, rne forces) stop here: no body above this depth carries a dof
@@ -936,6 +948,7 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
   for (int D = 0; D < TP_MAXD + 2; D++) c.nchild[D] = t.lvl_dchild[D];
 
   // per-lane model constants
+  const double* const lk = t.lane_k + l * TPK_N;  // the lane's record of per-step constants
   const int jtype = m.jnt_type[j];
   const double mass = isb ? m.body_mass[b] : 0.0, qpos0 = m.qpos0[j];
   const double damping = has_dof ? m.dof_damping[j] : 0.0;
@@ -970,8 +983,8 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
       // quaternion/vector compose per tree level
       // pose constants of the lane's body and joint are re-read every step (cache hits) rather
       // than held in 26 registers across the whole kernel
-      const V3 bpos = ld3(m.body_pos + 3 * b), jpos = ld3(m.jnt_pos + 3 * j), jax = ld3(m.jnt_axis + 3 * j);
-      const Q4 bquat = ld4(m.body_quat + 4 * b);
+      const V3 bpos = ld3(lk + TPK_BPOS), jpos = ld3(lk + TPK_JPOS), jax = ld3(lk + TPK_JAX);
+      const Q4 bquat = ld4(lk + TPK_BQUAT);
       const double dq = qpos - qpos0;
       Q4 lq = bquat;
       V3 lp = bpos;
@@ -1010,7 +1023,7 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
       // ---- A2 comPos
       V3 xipos;
       {
-        const V3 ip = mrot(xmat, ld3(m.body_ipos + 3 * b));
+        const V3 ip = mrot(xmat, ld3(lk + TPK_IPOS));
         xipos = {pos.x + ip.x, pos.y + ip.y, pos.z + ip.z};
       }
       V3 com = {0, 0, 0};
@@ -1029,8 +1042,8 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
       }
       double cinert[10], cdof[6];
       {
-        const M3 R = q2m(qmul(quat, ld4(m.body_iquat + 4 * b)));
-        const double* I = m.body_inertia + 3 * b;
+        const M3 R = q2m(qmul(quat, ld4(lk + TPK_IQUAT)));
+        const double* I = lk + TPK_INERTIA;
         const double off[3] = {xipos.x - com.x, xipos.y - com.y, xipos.z - com.z};
         double tt[9];
 #pragma unroll
@@ -1121,7 +1134,7 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
         double s0 = 0;
 #pragma unroll
         for (int k = 0; k < 6; k++) s0 += cdof[k] * buf[k];
-        Mr.r[0] = has_dof ? m.dof_armature[j] + s0 : 1.0;
+        Mr.r[0] = has_dof ? lk[TPK_ARMATURE] + s0 : 1.0;
 #pragma unroll
         for (int a = 1; a < TP_MAXD; a++) {
           Mr.r[a] = 0;
@@ -1155,15 +1168,15 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
       double qfrc_passive = 0, act_force = 0, qfrc_actuator = 0;
       {
         // joint and actuator constants from the per-lane table: one round of loads, no dependent branches
-        const double* pc = t.lane_d + l;
+        const double* pc = lk + TPK_D0;
         if (has_dof && !(m.disableflags & BS_DSBL_PASSIVE))
-          qfrc_passive = -pc[TPD_STIFF * TP_LPE] * (qpos - pc[TPD_SPRING * TP_LPE]) - damping * qvel;
+          qfrc_passive = -pc[TPD_STIFF] * (qpos - pc[TPD_SPRING]) - damping * qvel;
         if (act >= 0 && !(m.disableflags & BS_DSBL_ACTUATION)) {
-          const double gear = pc[TPD_ACT_GEAR * TP_LPE];
-          const double cc = fmin(fmax(ctrl, pc[TPD_ACT_CLO * TP_LPE]), pc[TPD_ACT_CHI * TP_LPE]);
-          double f = pc[TPD_ACT_GAIN * TP_LPE] * cc + pc[TPD_ACT_B0 * TP_LPE] + pc[TPD_ACT_B1 * TP_LPE] * (gear * qpos) +
-                     pc[TPD_ACT_B2 * TP_LPE] * (gear * qvel);
-          f = fmin(fmax(f, pc[TPD_ACT_FLO * TP_LPE]), pc[TPD_ACT_FHI * TP_LPE]);
+          const double gear = pc[TPD_ACT_GEAR];
+          const double cc = fmin(fmax(ctrl, pc[TPD_ACT_CLO]), pc[TPD_ACT_CHI]);
+          double f = pc[TPD_ACT_GAIN] * cc + pc[TPD_ACT_B0] + pc[TPD_ACT_B1] * (gear * qpos) +
+                     pc[TPD_ACT_B2] * (gear * qvel);
+          f = fmin(fmax(f, pc[TPD_ACT_FLO]), pc[TPD_ACT_FHI]);
           act_force = f;
           qfrc_actuator = gear * f;
         }
@@ -1348,25 +1361,25 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
       r.Df = r.rf = r.aref_f = r.fl = 0; r.Dl0 = r.Dl1 = r.aref_l0 = r.aref_l1 = 0;
       r.De = r.aref_e = r.ce = 0; r.De_o = r.ce_o = 0; r.own = false; r.cD = cDrow;
       int nact = 0;
-      const double* rc = t.lane_d + l;  // state-independent parts of the rows (host, build_tp)
+      const double* rc = lk + TPK_D0;  // state-independent parts of the rows (host, build_tp)
       if (con_on && has_dof) {
-        const double iw = rc[TPD_IW * TP_LPE], Df = rc[TPD_FRIC_D * TP_LPE], K = rc[TPD_LIM_K * TP_LPE];
+        const double iw = rc[TPD_IW], Df = rc[TPD_FRIC_D], K = rc[TPD_LIM_K];
         if (Df > 0) {
-          r.Df = Df; r.fl = rc[TPD_FRIC_FL * TP_LPE]; r.rf = rc[TPD_FRIC_RF * TP_LPE];
-          r.aref_f = -rc[TPD_FRIC_B * TP_LPE] * qvel;
+          r.Df = Df; r.fl = rc[TPD_FRIC_FL]; r.rf = rc[TPD_FRIC_RF];
+          r.aref_f = -rc[TPD_FRIC_B] * qvel;
           nact++;
         }
         if (K >= 0) {
-          const double margin = m.jnt_margin[j], B = rc[TPD_LIM_B * TP_LPE];
-          const double d0 = qpos - m.jnt_range[2 * j], d1 = m.jnt_range[2 * j + 1] - qpos;
+          const double margin = lk[TPK_JMARGIN], B = rc[TPD_LIM_B];
+          const double d0 = qpos - lk[TPK_JRANGE], d1 = lk[TPK_JRANGE + 1] - qpos;
           if (d0 < margin) {
-            const double imp = tp_impedance(m.jnt_solimp + 5 * j, d0, margin);
+            const double imp = tp_impedance(lk + TPK_JSOLIMP, d0, margin);
             r.Dl0 = 1.0 / fmax(BS_MINVAL, (1 - imp) * iw / imp);
             r.aref_l0 = -B * qvel - K * imp * (d0 - margin);
             nact++;
           }
           if (d1 < margin) {
-            const double imp = tp_impedance(m.jnt_solimp + 5 * j, d1, margin);
+            const double imp = tp_impedance(lk + TPK_JSOLIMP, d1, margin);
             r.Dl1 = 1.0 / fmax(BS_MINVAL, (1 - imp) * iw / imp);
             r.aref_l1 = B * qvel - K * imp * (d1 - margin);
             nact++;
@@ -1377,13 +1390,12 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
         // equality rows live on joint1's lane and need qpos/qvel of joint2 (an ancestor dof)
         const double qo = bperm(qpos, eq_other_sa), vo = bperm(qvel, eq_other_sa);
         if (con_on && eq_own >= 0) {
-          const int jo = m.eq_jnt2[eq_own];
-          const double* cf = m.eq_data + 5 * eq_own;
-          const double x = qo - m.qpos0[jo];
+          const double* cf = lk + TPK_EQDATA;
+          const double x = qo - lk[TPK_EQQPOS0];
           const double pos_e = (qpos - qpos0) - (cf[0] + x * (cf[1] + x * (cf[2] + x * (cf[3] + x * cf[4]))));
           const double deriv = cf[1] + x * (2 * cf[2] + x * (3 * cf[3] + x * 4 * cf[4]));
-          const double diag = rc[TPD_EQ_DIAG * TP_LPE], K = rc[TPD_EQ_K * TP_LPE], B = rc[TPD_EQ_B * TP_LPE];
-          const double imp = tp_impedance(m.eq_solimp + 5 * eq_own, pos_e, 0.0);
+          const double diag = rc[TPD_EQ_DIAG], K = rc[TPD_EQ_K], B = rc[TPD_EQ_B];
+          const double imp = tp_impedance(lk + TPK_EQSOLIMP, pos_e, 0.0);
           r.own = true; r.ce = deriv; r.De = 1.0 / fmax(BS_MINVAL, (1 - imp) * diag / imp);
           r.aref_e = -B * (qvel - deriv * vo) - K * imp * pos_e;
           nact++;
