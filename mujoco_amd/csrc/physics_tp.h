@@ -214,6 +214,8 @@ struct TpCtx {
   int dd;                // entries in this dof's row (0 = no dof on this lane)
   int maxdd;
   int nchild[TP_MAXD + 2];  // lvl_dchild
+  int dchild0;           // first entry of the lane's dof-child list (the LDS table's row 0): most levels have one child,
+                         // so the sweeps' usual case needs no table read in front of the permutes
   tp_lds_ptr tbl;        // LDS table
 };
 
@@ -249,7 +251,7 @@ __device__ TP_HELPER_ATTR TpFac tp_factor(TpCtx c, TpRow Rin) {
     if (D == 1) break;
     const bool par = c.dd == D - 1;
     for (int ch = 0; ch < c.nchild[D]; ch++) {
-      const int src = c.tbl[(TPL_DCHILD + ch) * 64 + threadIdx.x];
+      const int src = ch == 0 ? c.dchild0 : c.tbl[(TPL_DCHILD + ch) * 64 + threadIdx.x];
       const int sa = par && src >= 0 ? src : c.zero_sa;
 #pragma unroll
       for (int a = 1; a < TP_MAXD; a++) {
@@ -304,7 +306,7 @@ __device__ TP_HELPER_ATTR double tp_factor_solve(TpCtx c, TpRow Rin, double x) {
     if (D == 1) break;
     const bool par = c.dd == D - 1;
     for (int ch = 0; ch < c.nchild[D]; ch++) {
-      const int src = c.tbl[(TPL_DCHILD + ch) * 64 + threadIdx.x];
+      const int src = ch == 0 ? c.dchild0 : c.tbl[(TPL_DCHILD + ch) * 64 + threadIdx.x];
       const int sa = par && src >= 0 ? src : c.zero_sa;
 #pragma unroll
       for (int a = 1; a < TP_MAXD; a++) {
@@ -372,7 +374,7 @@ __device__ TP_HELPER_ATTR void tp_factor2(TpCtx c, TpRow R0in, TpRow R1in, TpFac
     if (D == 1) break;
     const bool par = c.dd == D - 1;
     for (int ch = 0; ch < c.nchild[D]; ch++) {
-      const int src = c.tbl[(TPL_DCHILD + ch) * 64 + threadIdx.x];
+      const int src = ch == 0 ? c.dchild0 : c.tbl[(TPL_DCHILD + ch) * 64 + threadIdx.x];
       const int sa = par && src >= 0 ? src : c.zero_sa;
 #pragma unroll
       for (int a = 1; a < TP_MAXD; a++) {
@@ -410,7 +412,7 @@ __device__ TP_HELPER_ATTR double tp_solve(TpCtx c, TpRow Rin, double dinv, doubl
     for (int a = 1; a < TP_MAXD; a++)
       if (a < D) T[a] = is ? R[a] * x + W[a] : 0.0;
     for (int ch = 0; ch < c.nchild[D]; ch++) {
-      const int src = c.tbl[(TPL_DCHILD + ch) * 64 + threadIdx.x];
+      const int src = ch == 0 ? c.dchild0 : c.tbl[(TPL_DCHILD + ch) * 64 + threadIdx.x];
       const int sa = par && src >= 0 ? src : c.zero_sa;
 #pragma unroll
       for (int a = 1; a < TP_MAXD; a++) {
@@ -460,7 +462,7 @@ __device__ TP_HELPER_ATTR double tp_solve_mulm(TpCtx c, TpRow Rin, double dinv, 
     for (int a = 1; a < TP_MAXD; a++)
       if (a < D) { T[a] = is ? R[a] * x + W[a] : 0.0; U[a] = is ? Mr[a] * v + V[a] : 0.0; }
     for (int ch = 0; ch < c.nchild[D]; ch++) {
-      const int src = c.tbl[(TPL_DCHILD + ch) * 64 + threadIdx.x];
+      const int src = ch == 0 ? c.dchild0 : c.tbl[(TPL_DCHILD + ch) * 64 + threadIdx.x];
       const int sa = par && src >= 0 ? src : c.zero_sa;
 #pragma unroll
       for (int a = 1; a < TP_MAXD; a++) {
@@ -507,7 +509,7 @@ __device__ TP_HELPER_ATTR void tp_solve_n(TpCtx c, TpRow Rin, double dinv, doubl
       for (int a = 1; a < TP_MAXD; a++)
         if (a < D) T[n][a] = is ? R[a] * x[n] + W[n][a] : 0.0;
     for (int ch = 0; ch < c.nchild[D]; ch++) {
-      const int src = c.tbl[(TPL_DCHILD + ch) * 64 + threadIdx.x];
+      const int src = ch == 0 ? c.dchild0 : c.tbl[(TPL_DCHILD + ch) * 64 + threadIdx.x];
       const int sa = par && src >= 0 ? src : c.zero_sa;
 #pragma unroll
       for (int a = 1; a < TP_MAXD; a++) {
@@ -561,7 +563,7 @@ __device__ TP_HELPER_ATTR double tp_mul_m(TpCtx c, TpRow Min, double v) {
     for (int a = 1; a < TP_MAXD; a++)
       if (a < D) T[a] = is ? Mr[a] * v + W[a] : 0.0;
     for (int ch = 0; ch < c.nchild[D]; ch++) {
-      const int src = c.tbl[(TPL_DCHILD + ch) * 64 + threadIdx.x];
+      const int src = ch == 0 ? c.dchild0 : c.tbl[(TPL_DCHILD + ch) * 64 + threadIdx.x];
       const int sa = par && src >= 0 ? src : c.zero_sa;
 #pragma unroll
       for (int a = 1; a < TP_MAXD; a++) {
@@ -939,6 +941,8 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
   const int b = l < m.nbody ? l : 0, j = has_dof ? jnt : 0;
   TpCtx c;
   c.self_sa = self_sa; c.zero_sa = (base + TP_LPE - 1) * 4; c.dd = has_dof ? t.lane[TPI_DD * TP_LPE + l] : 0; c.maxdd = t.maxdd; c.tbl = (tp_lds_ptr)tbl;
+  c.dchild0 = lane_ref(TPI_DCHILD);
+  const int bchild0 = lane_ref(TPI_BCHILD);
 #pragma unroll
   for (int a = 0; a < TP_MAXD; a++) {
     const int v = lane_ref(TPI_ANC + a);
@@ -1117,7 +1121,7 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
         for (int lvl = t.maxdepth; lvl >= (FULL ? 2 : t.fold_minlvl); lvl--) {
           const bool par = isb && depth == lvl - 1;
           for (int ch = 0; ch < t.lvl_bchild[lvl]; ch++) {
-            const int src = tbl[(TPL_BCHILD + ch) * 64 + tid];
+            const int src = ch == 0 ? bchild0 : tbl[(TPL_BCHILD + ch) * 64 + tid];
             const int sa = par && src >= 0 ? src : c.zero_sa;
 #pragma unroll
             for (int k = 0; k < 10; k++) crb[k] += bperm(crb[k], sa);
