@@ -865,8 +865,12 @@ static void launch_step(bs_sim* s, int n_steps) {
     const bool rk = s->dm.integrator == 1;
     auto* launch = s->dm.solver == 0 ? (rk ? bs_launch_tp_rk4_pgs : bs_launch_tp_pgs)
                    : s->dm.solver == 1 ? (rk ? bs_launch_tp_rk4_cg : bs_launch_tp_cg) : (rk ? bs_launch_tp_rk4 : bs_launch_tp);
+    int dump = 1;
+#ifdef TPC_CUTS
+    if (const char* e = getenv("BS_CUT")) dump |= (atoi(e) + 1) << 8;
+#endif
     launch(grid_tp(s), s->dm.solver == 0 ? (size_t)2 * s->dm.nbody * tp_minv_stride(s->dm.nbody) * sizeof(double) : 0, s->stream,
-           s->dm, s->tp, s->dd, n_steps, 0, 1);
+           s->dm, s->tp, s->dd, n_steps, 0, dump);
   } else {
     bs_launch_step(grid_for(s), s->stream, s->dm, s->dd, n_steps);
   }

@@ -83,6 +83,9 @@ struct TpModel {
   int lvl_dchild[TP_MAXD + 2]; // max #dof-children over dofs with dd == D-1, indexed by D
 };
 
+// sincos out of line: inlined into the step loop, its polynomial coefficients are hoisted out of the loop as
+// register pairs, spilled, and reloaded from scratch one dependent round trip at a time inside every call
+__device__ __attribute__((noinline)) void tp_sincos(double x, double* sn, double* cs) { sincos(x, sn, cs); }
 // ---- cross-lane primitives.  `sa` arguments are ds_bpermute byte addresses (lane * 4).
 __device__ __forceinline__ double bperm(double v, int sa) {
   const int lo = __builtin_amdgcn_ds_bpermute(sa, __double2loint(v));
@@ -998,7 +1001,7 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
           lp = {bpos.x + s.x * dq, bpos.y + s.y * dq, bpos.z + s.z * dq};
         } else {
           double sn, cs;
-          sincos(0.5 * dq, &sn, &cs);
+          tp_sincos(0.5 * dq, &sn, &cs);
           const Q4 qj = {cs, jax.x * sn, jax.y * sn, jax.z * sn};
           lq = qmul(bquat, qj);
           const V3 rj = mrot(q2m(qj), jpos);
