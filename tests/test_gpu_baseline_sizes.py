@@ -14,13 +14,16 @@ pytestmark = pytest.mark.gpu
 
 def _samples(E, extra=()):
     """>= 32 environment ids on the boundaries named above."""
-    chunk = (E // 2 + 63) // 64 * 64  # split_chunk(E, 2) of batchsim.hip
     ids = {0, 1, 2, 3, 62, 63, 64, 65, 126, 127, 128, 129, E - 1, E - 2, E - 64, E - 65, E // 2 - 1, E // 2,
-           chunk - 1, chunk, chunk + 1, chunk - 64, E // 3, 2 * E // 3, E // 5, 4 * E // 5}
+           E // 3, 2 * E // 3, E // 5, 4 * E // 5}
+    for np_ in (2, 3):  # range boundaries of split_chunk(E, np) in batchsim.hip (default: 2 ranges from 16 384 envs, 3 from 49 152)
+        chunk = (E // np_ + 63) // 64 * 64
+        for q in range(1, np_):
+            ids |= {q * chunk - 64, q * chunk - 1, q * chunk, q * chunk + 1}
     ids |= {2 * 64 * k + 2 * (k % 7) for k in range(1, 8)}   # different work-list sub-lists, later rounds of blocks
     ids |= set(extra)
     rng = np.random.default_rng(E)
-    while len(ids) < 36:
+    while len(ids) < 40:
         ids.add(int(rng.integers(0, E)))
     return sorted(i for i in ids if 0 <= i < E)
 
