@@ -162,6 +162,12 @@ int bs_reset_noalloc(bs_sim *s, const uint8_t *env_mask);
 int bs_state_rows(const bs_sim *s, int *rows);
 int bs_get_state(bs_sim *s, double *dev_buf, int64_t ld);
 int bs_set_state(bs_sim *s, const double *dev_buf, int64_t ld);
+/* Which kernel family bs_step runs for this sim: returns 1 and writes "tree-parallel (...)" when the model is
+ * eligible for the one-lane-per-body kernels, 0 and "serial (...): <reason>" when it runs the generic
+ * one-environment-per-lane kernels (about 40x slower: more than 31 bodies, two joints on a body, dof depth
+ * above 6, ...), < 0 (a bs_status) on error.  No counterpart in the reference (MuJoCo has one code path);
+ * mujoco_amd.BatchSim warns once when the answer is 0. */
+int bs_sim_kernel_path(const bs_sim *s, char *buf, int cap);
 /* The stream the sim's kernels are enqueued on (its own, or the one given to bs_set_stream). */
 int bs_get_stream(bs_sim *s, void **hip_stream);
 

@@ -1107,6 +1107,24 @@ extern "C" int bs_sim_create(const bs_model* const* models, int n_models, const 
   return BS_OK;
 }
 
+// which kernel family bs_step runs for this sim, and why if it is the slow generic one
+extern "C" int bs_sim_kernel_path(const bs_sim* s, char* buf, int cap) {
+  if (!s || !buf || cap < 1) return fail(BS_ERR_INVALID, "bs_sim_kernel_path: null argument");
+  const bool tp = s->contacts ? s->use_tpc : s->use_tp;
+  const char* kv = getenv("BS_KERNEL");
+  std::string why;
+  if (!tp) {
+    if (!s->model->tp_ok) why = s->model->tp_why;
+    else if (kv && strcmp(kv, "serial") == 0) why = "BS_KERNEL=serial";
+    else if (s->contacts && s->cm.maxcon > TP_LPE) why = "more than 32 contacts per environment requested";
+    else why = "not selected";
+  }
+  snprintf(buf, (size_t)cap, "%s%s%s", tp ? (s->contacts ? "tree-parallel (k_tp_col, k_c_narrow_list, k_tpc)" : "tree-parallel (k_tp)")
+                                             : (s->contacts ? "serial (k_c_pos, k_c_broad, k_c_narrow_flat, k_c_dyn): " : "serial (k_step): "),
+           why.c_str(), "");
+  return tp ? 1 : 0;
+}
+
 extern "C" int bs_sim_destroy(bs_sim* s) {
   if (!s) return BS_OK;
   (void)hipSetDevice(s->device);

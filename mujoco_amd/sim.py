@@ -224,6 +224,11 @@ class BatchSim:
         _abi.check(L.bs_sim_create(models, 1, None, self.n_envs, self.device_id, C.byref(opt), C.byref(h)))
         self._h = h
         self.data = BatchData(self)
+        fast, path = self.kernel_path()
+        if not fast:
+            import warnings
+            warnings.warn("mujoco_amd: this model runs on the generic one-environment-per-lane kernels, about 40x "
+                          "slower than the tree-parallel ones: " + path, RuntimeWarning, stacklevel=2)
         if use_torch_stream:
             import torch
             with torch.cuda.device(self.device_id):
@@ -337,6 +342,14 @@ class BatchSim:
             buf[cut[i]:cut[i + 1]].copy_(val.T)
         _abi.check(_abi.lib().bs_set_state(self._h, C.c_void_p(buf.data_ptr()), E))
         self._keep_state = buf  # alive until the copies have run
+
+    def kernel_path(self):
+        """(fast, description): which kernel family bs_step runs for this sim (bs_sim_kernel_path)."""
+        buf = C.create_string_buffer(256)
+        rc = _abi.lib().bs_sim_kernel_path(self._h, buf, 256)
+        if rc < 0:
+            _abi.check(rc)
+        return bool(rc), buf.value.decode()
 
     def stream_handle(self):
         """The hipStream_t the sim's kernels are enqueued on (bs_get_stream)."""

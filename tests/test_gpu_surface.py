@@ -249,3 +249,29 @@ def test_forward_cg_pgs_on_tree_parallel_kernels(hand_model, solver, monkeypatch
         s.qpos[:] = q[e]; s.qvel[:] = v[e]; s.ctrl[:] = c[e]
         s.forward()
         assert np.abs(a["qacc"][e] - s.qacc).max() / max(1.0, np.abs(s.qacc).max()) < 1e-8, e
+
+
+def test_kernel_path_is_reported_and_fallback_warns(hand_model, monkeypatch):
+    """bs_sim_kernel_path: an eligible model runs the tree-parallel kernels; the generic fallback is
+    not silent (BatchSim warns, the reason is readable)."""
+    import warnings
+    from mujoco_amd import BatchSim, workload
+
+    free = workload.contact_free(hand_model)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        sim = BatchSim(free, n_envs=4)
+        fast, path = sim.kernel_path()
+        assert fast and "k_tp" in path
+        sim.close()
+        sim = BatchSim(hand_model, n_envs=4)
+        fast, path = sim.kernel_path()
+        assert fast and "k_tpc" in path
+        sim.close()
+    monkeypatch.setenv("BS_KERNEL", "serial")
+    with pytest.warns(RuntimeWarning, match="generic one-environment-per-lane"):
+        sim = BatchSim(free, n_envs=4)
+    fast, path = sim.kernel_path()
+    assert not fast and "BS_KERNEL=serial" in path and "k_step" in path
+    sim.close()
+    monkeypatch.delenv("BS_KERNEL")
