@@ -163,6 +163,14 @@ class Workload:
             done += n
             self.period += 1
 
+    def close(self):
+        """Destroy the sim NOW (BatchSim <-> BatchData is a reference cycle, so `del` alone leaves its streams
+        alive until the cyclic collector runs: with GPU_MAX_HW_QUEUES = 4 the three streams of the next contact
+        sim would then share hardware queues and its ranges would not overlap: measured 2.86 instead of 2.38 ms/step)."""
+        self.gather = None
+        self.launch_events = []
+        self.sim.close()
+
     def fence(self):
         if self.gather is not None:
             self.gather.wait()
@@ -260,6 +268,7 @@ def contacts_block(model_path, E, local_rank, seed, steps, warmup, world, dist, 
             blk["cpu_baseline_allcores"] = cpu_baseline_allcores(model_path, True)
         except Exception as ex:
             blk["cpu_baseline_allcores"] = {"error": repr(ex)}
+    w.close()
     del w
     torch.cuda.empty_cache()
     return blk
@@ -458,6 +467,7 @@ def main():
                 out["cpu_baseline_allcores"] = cpu_baseline_allcores(model_path, args.contacts)
             except Exception as ex:  # the pool is informational; the single-thread figure is the contract
                 out["cpu_baseline_allcores"] = {"error": repr(ex)}
+    w.close()
     del w
     torch.cuda.empty_cache()
     if plain and world == 1 and not args.no_extra_blocks:

@@ -63,7 +63,10 @@ class BatchData:
     """`sim.data` — device views named after mjData members."""
 
     def __init__(self, sim):
-        object.__setattr__(self, "_sim", sim)
+        # weak: sim.data <-> sim must not be a reference cycle, or `del sim` would leave the native sim (its
+        # arenas and streams) alive until the cyclic collector runs
+        import weakref
+        object.__setattr__(self, "_sim", weakref.proxy(sim))
         object.__setattr__(self, "_cache", {})
 
     def _view(self, name):
