@@ -259,7 +259,7 @@ def contacts_block(model_path, E, local_rank, seed, steps, warmup, world, dist, 
                                      if gather_world else "none"),
                       "collision": cstat, **stats},
            "roofline": roofline_block(m["launches"], E, flop, "k_tp_col + k_c_narrow_list + k_tpc (one step = 3 launches per range, "
-                                      "2 ranges on 2 streams)", traffic, src,
+                                      "3 ranges on 3 streams from 49 152 envs)", traffic, src,
                                       "flop model F = 36k + 12k N_np + 6k ncon n_iter with the measured N_np / ncon / n_iter of this run; "
                                       "duration = HIP events around every bs_step call of the timed regions; traffic = per step, all three kernels")}
     if with_cpu:

@@ -38,13 +38,13 @@ for tag, ds in (("config1_pmc_per_launch", ["p_tp_fetch", "p_tp_write", "p_tp_sq
         for k, v in agg(d).items():
             m[k].update(v)
     out[tag] = m
-# one step of the contact path = one launch of each of the three kernels per range (two ranges of 32768 envs):
-# per-step traffic = 2 x the per-launch averages
-out["contacts_pmc_per_step"] = {k: {a: 2 * b for a, b in v.items() if a in ("FETCH_SIZE", "WRITE_SIZE")}
+# one step of the contact path = one launch of each of the three kernels per range (three ranges of about
+# 21 800 envs at 65 536): per-step traffic = 3 x the per-launch averages
+out["contacts_pmc_per_step"] = {k: {a: 3 * b for a, b in v.items() if a in ("FETCH_SIZE", "WRITE_SIZE")}
                                 for k, v in out["contacts_pmc_per_launch"].items() if k in ("k_tp_col", "k_c_narrow_list", "k_tpc")}
 out["notes"] = ("per-launch averages over all dispatches of the kernel. config1 = `python3 bench.py --steps 500 --warmup 100 "
                 "--no-cpu-baseline --no-extra-blocks` (k_tp: 50 steps x 4096 envs per launch); contacts = `python3 bench.py --contacts --envs 65536 "
-                "--steps 50 --warmup 50 --no-cpu-baseline` (one step per launch, two ranges of 32768 envs on two streams). "
+                "--steps 50 --warmup 50 --no-cpu-baseline` (one step per launch, three ranges of about 21 800 envs on three streams). "
                 "FETCH_SIZE / WRITE_SIZE in KB as rocprofv3 reports them; HBM-side traffic estimate = (2 x FETCH_SIZE + "
                 "WRITE_SIZE) x 1024 B (gfx950 FETCH_SIZE halving, MI355X_MICROARCH.md; strided 8-byte accesses are "
                 "uncalibrated). SQ_*CYCLES and SQ_WAIT/ACTIVE counters are in quad-cycles.")
