@@ -911,6 +911,18 @@ extern "C" int bs_sim_create(const bs_model* const* models, int n_models, const 
     }
     top->stream = top->own_stream;
     for (bs_sim* c : top->parts) c->stream = top->stream;
+    // parts 1 and 2 step on their own streams, forked from / joined to the sim's stream by these events: a
+    // part of a few thousand environments leaves most of the machine idle (BS_MIXED_SERIAL=1: one after the other)
+    const char* ms = getenv("BS_MIXED_SERIAL");
+    if (top->parts.size() > 1 && !(ms && atoi(ms))) {
+      bool ok = hipEventCreateWithFlags(&top->fork_ev, hipEventDisableTiming) == hipSuccess;
+      for (int q = 0; q < 2 && ok; q++) ok = hipEventCreateWithFlags(&top->join_ev[q], hipEventDisableTiming) == hipSuccess;
+      if (!ok) {
+        bs_sim_destroy(top);
+        return fail(BS_ERR_HIP, "bs_sim_create: cannot create the events of the mixed-model sim");
+      }
+      top->split = 2;  // marks the concurrent mode
+    }
     *out = top;
     return BS_OK;
   }
@@ -1181,7 +1193,25 @@ extern "C" int bs_step(bs_sim* s, int n_steps) {
   if (n_steps == 0) return BS_OK;
   HIPCHK(hipSetDevice(s->device));
   if (!s->parts.empty()) {
-    for (bs_sim* c : s->parts) launch_step(c, n_steps);
+    if (s->split > 1) {
+      HIPCHK(hipEventRecord(s->fork_ev, s->stream));
+      for (size_t k = 0; k < s->parts.size(); k++) {
+        bs_sim* c = s->parts[k];
+        // contact steps are sequences of short launches with gaps between them; a contact-free part is one long
+        // launch that fills the machine by itself (measured: PGS 29.0 M serial, 24.7 M concurrent)
+        const bool aside = (k == 1 || k == 2) && c->contacts;
+        hipStream_t st = aside ? c->own_stream : s->stream;
+        if (aside) HIPCHK(hipStreamWaitEvent(st, s->fork_ev, 0));
+        c->stream = st;
+        launch_step(c, n_steps);
+        c->stream = s->stream;
+        if (aside) HIPCHK(hipEventRecord(s->join_ev[k - 1], st));
+      }
+      for (size_t k = 1; k < s->parts.size() && k <= 2; k++)
+        if (s->parts[k]->contacts) HIPCHK(hipStreamWaitEvent(s->stream, s->join_ev[k - 1], 0));
+    } else {
+      for (bs_sim* c : s->parts) launch_step(c, n_steps);
+    }
     HIPCHK(hipGetLastError());
     return BS_OK;
   }
