@@ -1097,7 +1097,7 @@ extern "C" int bs_sim_create(const bs_model* const* models, int n_models, const 
     // ranges of a contact batch run on separate streams; every range is a whole number of 64-env
     // blocks and non-empty (the count is lowered until that holds)
     const char* sp = getenv("BS_SPLIT");
-    int np = sp ? atoi(sp) : (n_envs >= 49152 ? 3 : n_envs >= 16384 ? 2 : 1);  // measured: 3 ranges win from 65 536 envs (27.5 vs 26.9 M env-steps/s), 4 lose
+    int np = sp ? atoi(sp) : (n_envs >= 8192 ? 3 : 1);  // measured: 3 ranges win from 8192 envs (14.6 vs 12.7 M env-steps/s; 27.5 vs 26.9 M at 65 536), 4 lose
     np = np < 1 ? 1 : (np > 4 ? 4 : np);
     if (!s->use_tpc || s->dm.integrator == 1) np = 1;
     while (np > 1 && (n_envs < 128L * np || split_chunk(n_envs, np) * (np - 1) >= n_envs)) np--;

@@ -17,7 +17,9 @@
 #define NL_OCC 2        // wavefronts per SIMD k_c_narrow_list is compiled for (register budget 512 / NL_OCC)
 #endif
 #ifndef NL_MIN_SHARE
-#define NL_MIN_SHARE 192  // least number of work-list items a wavefront of k_c_narrow_list takes
+#define NL_MIN_SHARE 64   // least number of work-list items a wavefront of k_c_narrow_list takes: one per lane.  Only small
+                          // batches come down to it (a share is total / grid otherwise); 192 made their few wavefronts
+                          // work through three items per lane in sequence: 4096 envs 7.9 -> 10.6 M env-steps/s
 #endif
 #ifndef TPC_OCC
 #define TPC_OCC 2

@@ -16,7 +16,7 @@ def _samples(E, extra=()):
     """>= 32 environment ids on the boundaries named above."""
     ids = {0, 1, 2, 3, 62, 63, 64, 65, 126, 127, 128, 129, E - 1, E - 2, E - 64, E - 65, E // 2 - 1, E // 2,
            E // 3, 2 * E // 3, E // 5, 4 * E // 5}
-    for np_ in (2, 3):  # range boundaries of split_chunk(E, np) in batchsim.hip (default: 2 ranges from 16 384 envs, 3 from 49 152)
+    for np_ in (2, 3):  # range boundaries of split_chunk(E, np) in batchsim.hip (default: 3 ranges from 8192 envs; BS_SPLIT=2 in the split test)
         chunk = (E // np_ + 63) // 64 * 64
         for q in range(1, np_):
             ids |= {q * chunk - 64, q * chunk - 1, q * chunk, q * chunk + 1}
