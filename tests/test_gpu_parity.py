@@ -699,6 +699,38 @@ def test_three_exported_hands_in_one_batch():
     sim.close()
 
 
+def test_mixed_parts_concurrent_is_bitwise_neutral(monkeypatch):
+    """The parts of a mixed-model sim with contacts step on their own streams (forked from and joined to
+    the sim's stream); BS_MIXED_SERIAL=1 runs them one after the other.  Same bits, and work enqueued on
+    the sim's stream afterwards (reset, a later step) sees the finished parts."""
+    import os
+    import torch
+    from mujoco_amd import MixedBatchSim, Model, workload
+    g = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    models = [Model.load(os.path.join(g, n)) for n in ("dexterous_model.npz", "hand_1120.npz", "hand_1206.npz")]
+    out = {}
+    for mode in ("concurrent", "serial"):
+        if mode == "serial":
+            monkeypatch.setenv("BS_MIXED_SERIAL", "1")
+        sim = MixedBatchSim(models, counts=[70, 130, 66])
+        for k, p in enumerate(sim.parts):
+            q, v = workload.config2_state(models[k], p.n_envs, seed=90 + k)
+            c = workload.config2_ctrl(models[k], p.n_envs, seed=90 + k)
+            p.data.qpos.copy_(torch.as_tensor(q)); p.data.ctrl.copy_(torch.as_tensor(c))
+        for _ in range(3):
+            sim.step(7)
+            sim.step(1)
+        sim.sync()
+        out[mode] = [(p.data.qpos.cpu().numpy().copy(), p.data.qvel.cpu().numpy().copy(), p.data.qacc.cpu().numpy().copy(),
+                      p.data.ncon.cpu().numpy().copy()) for p in sim.parts]
+        sim.close()
+    monkeypatch.delenv("BS_MIXED_SERIAL")
+    for a, b in zip(out["concurrent"], out["serial"]):
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
+    assert sum(int(a[3].sum()) for a in out["concurrent"]) > 0
+
+
 def test_vec_env_rollout(hand_model):
     """RL glue: observation / reward definitions, frame skip, device-side
     auto-reset; the physics under it is the same bs_step as everywhere else."""
