@@ -570,6 +570,19 @@ static int model_image(bs_model* m, int device, const DeviceImage** out) {
     r[10] = 2 * mue * mue;
     pbody[2 * p] = b1 | (dim << 16); pbody[2 * p + 1] = b2;
   }
+  std::vector<int32_t> pnp((size_t)(s.npair > 0 ? s.npair : 1) * 8, 0);
+  for (int p = 0; p < s.npair; p++) {
+    const int g1 = s.pair_geom1[p], g2 = s.pair_geom2[p];
+    int32_t* r = &pnp[(size_t)p * 8];
+    const bool mesh1 = s.geom_type[g1] == BS_GEOM_MESH, mesh2 = s.geom_type[g2] == BS_GEOM_MESH;
+    const int m1 = mesh1 ? s.geom_dataid[g1] : 0, m2 = mesh2 ? s.geom_dataid[g2] : 0;
+    r[0] = g1 | ((s.geom_type[g1] == BS_GEOM_PLANE ? 1 : 0) << 16); r[1] = g2;
+    r[2] = s.nmesh > 0 ? s.mesh_vertadr[m1] : 0; r[3] = m1 * BS_NSTART;
+    r[4] = s.nmesh > 0 ? s.mesh_vertadr[m2] : 0; r[5] = m2 * BS_NSTART;
+    const double mg = fmax(s.geom_margin[g1], s.geom_margin[g2]);
+    memcpy(r + 6, &mg, sizeof mg);
+  }
+  PUT_CI(pair_np, pnp.data(), pnp.size());
   PUT_CD(pair_con, pcon.data(), pcon.size());
   PUT_CI(pair_body, pbody.data(), pbody.size());
   PUT_CD(hull_vert, s.hull_vert, s.nhullvert * 3);
@@ -725,6 +738,7 @@ struct bs_sim {
   bool mask_pending = false;
   size_t serial_rows = 0;   // rows of the serial contact solver's buffers (allocated on first use)
   void* sarena = nullptr;   // cJ / Hd / cW of the serial contact solver (ensure_serial_contact)
+  void* gframe = nullptr;   // ColData::gframe: geom frames as [E][ngeom][12] for the persistent narrowphase
   // mixed-model batch: one child sim per model over a contiguous range of environments (each with
   // its own arenas, since row counts differ between models); all run on this sim's stream
   // two halves of a contact batch on two streams: kernels of different kinds overlap (both the
@@ -1085,6 +1099,18 @@ extern "C" int bs_sim_create(const bs_model* const* models, int n_models, const 
       const int rc2 = ensure_serial_contact(s);
       if (rc2) { bs_sim_destroy(s); return rc2; }
     }
+    if (s->use_tpc && !s->narrow_ws && !s->narrow_blocks && !s->cm.has_prim) {
+      const size_t gbytes = (size_t)E * s->cm.ngeom * 12 * sizeof(double);
+      he = hipMalloc(&s->gframe, gbytes);
+      if (he != hipSuccess) {
+        s->gframe = nullptr;
+        bs_sim_destroy(s);
+        return fail(BS_ERR_NOMEM, "bs_sim_create: hipMalloc of %zu bytes for the geom frame records failed: %s", gbytes,
+                    hipGetErrorString(he));
+      }
+      HIPCHK_S(hipMemset(s->gframe, 0, gbytes));
+      c.gframe = (double*)s->gframe;
+    }
   } else {
     s->fields[BS_F_NCON] = {d.nefc, 0, true};  // zero rows: no contacts in this sim
   }
@@ -1159,6 +1185,7 @@ extern "C" int bs_sim_destroy(bs_sim* s) {
   if (s->mask_ev) (void)hipEventDestroy(s->mask_ev);
   if (s->mask_pinned) (void)hipHostFree(s->mask_pinned);
   if (s->sarena) (void)hipFree(s->sarena);
+  if (s->gframe) (void)hipFree(s->gframe);
   if (s->arena) (void)hipFree(s->arena);
   if (s->carena) (void)hipFree(s->carena);
   if (s->own_stream) (void)hipStreamDestroy(s->own_stream);

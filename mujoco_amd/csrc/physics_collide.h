@@ -53,6 +53,10 @@ struct ColModel {
   // dependent levels of per-geom loads): {margin - gap, mu, K, B, mixed solimp[5], diagApprox, 2 mu_e^2 (dim > 1), -}
   const double *pair_con;  // [npair][BS_PAIR_CON]
   const int *pair_body;    // [npair][2]: body of geom1 | condim << 16, body of geom2
+  // what the persistent narrowphase needs about a pair in one 32-byte record (instead of pair -> geoms ->
+  // mesh tables, three dependent levels of loads per item): geom1 | plane << 16, geom2, first vertex record and
+  // start-table row of hull 1 and of hull 2; the pair's margin = max of the geoms' follows as a double
+  const int *pair_np;      // [npair][8]: g1 | plane << 16, g2, vbase1, sbase1, vbase2, sbase2, margin (2 ints = one double)
   int nl_min_share;        // least number of work-list items a wavefront of k_c_narrow_list takes
   int has_prim;            // some pair involves a primitive geom: the narrowphase kernels' PRIM instantiation runs
 };
@@ -85,6 +89,10 @@ inline void bin_dir(int bin, double* d) {
 struct ColData {
   // geom frames (the sim's derived buffers)
   double *geom_xpos, *geom_xmat;
+  // ... and, for the persistent narrowphase of the tree-parallel path, the same frames as one record per
+  // environment and geom, [E][ngeom][12] = position | matrix (k_tp_col writes it INSTEAD of the arrays above):
+  // an item reads two contiguous 96-byte records where the [row][E] arrays cost 24 cache lines
+  double *gframe;
   // candidates [maxcand][E]
   int *ncand, *cand_pair, *cand_hit;
   // narrowphase work list of the tree-parallel path: (env - env0) << 8 | candidate slot.  The
@@ -820,28 +828,45 @@ __device__ inline void col_narrow_persistent(const ColModel& cm, const DevData& 
         const int it = items[lo * subcap + (i - pre[lo])];
         e = d.env0 + (it >> 8); slot = it & 255;
         const int p = AT(c.cand_pair, slot) & BS_PAIR_MASK;
-        const int g1 = cm.pair_geom1[p], g2 = cm.pair_geom2[p];
-        margin = fmax(cm.geom_margin[g1], cm.geom_margin[g2]);
-        const int mb = cm.geom_dataid[g2];
-        b.vbase = cm.mesh_vertadr[mb]; b.sbase = mb * BS_NSTART;
+        const int4 r0 = *(const int4*)(cm.pair_np + 8 * p), r1 = *(const int4*)(cm.pair_np + 8 * p + 4);
+        const int g1 = r0.x & 0xffff, g2 = r0.y;
+        plane = (r0.x >> 16) != 0;
+        margin = __hiloint2double(r1.w, r1.z);
+        b.vbase = r1.x; b.sbase = r1.y;
         b.cache = 0;
-        b.xpos = {AT(c.geom_xpos, 3 * g2), AT(c.geom_xpos, 3 * g2 + 1), AT(c.geom_xpos, 3 * g2 + 2)};
-        for (int k = 0; k < 9; k++) b.R.a[k] = AT(c.geom_xmat, 9 * g2 + k);
-        plane = cm.geom_type[g1] == BS_GEOM_PLANE;
+        // frames: one 96-byte record per geom (c.gframe) or the [row][E] arrays
+        const double* f1 = c.gframe ? c.gframe + ((size_t)e * cm.ngeom + g1) * 12 : nullptr;
+        const double* f2 = c.gframe ? c.gframe + ((size_t)e * cm.ngeom + g2) * 12 : nullptr;
+        if (f2) {
+          b.xpos = {f2[0], f2[1], f2[2]};
+          for (int k = 0; k < 9; k++) b.R.a[k] = f2[3 + k];
+        } else {
+          b.xpos = {AT(c.geom_xpos, 3 * g2), AT(c.geom_xpos, 3 * g2 + 1), AT(c.geom_xpos, 3 * g2 + 2)};
+          for (int k = 0; k < 9; k++) b.R.a[k] = AT(c.geom_xmat, 9 * g2 + k);
+        }
         iters = 0;
         if (plane) {
-          pn = {AT(c.geom_xmat, 9 * g1 + 2), AT(c.geom_xmat, 9 * g1 + 5), AT(c.geom_xmat, 9 * g1 + 8)};
-          pp = {AT(c.geom_xpos, 3 * g1), AT(c.geom_xpos, 3 * g1 + 1), AT(c.geom_xpos, 3 * g1 + 2)};
+          if (f1) {
+            pn = {f1[3 + 2], f1[3 + 5], f1[3 + 8]};
+            pp = {f1[0], f1[1], f1[2]};
+          } else {
+            pn = {AT(c.geom_xmat, 9 * g1 + 2), AT(c.geom_xmat, 9 * g1 + 5), AT(c.geom_xmat, 9 * g1 + 8)};
+            pp = {AT(c.geom_xpos, 3 * g1), AT(c.geom_xpos, 3 * g1 + 1), AT(c.geom_xpos, 3 * g1 + 2)};
+          }
           b.margin = 0;
           // the partner is not climbed (md_support's only_b): it points at the same hull so its start loads are valid
           a.vbase = b.vbase; a.sbase = b.sbase; a.cache = 0; a.margin = 0;
           M.d = pn;  // the hull is queried along -d
         } else {
-          const int ma = cm.geom_dataid[g1];
-          a.vbase = cm.mesh_vertadr[ma]; a.sbase = ma * BS_NSTART;
+          a.vbase = r0.z; a.sbase = r0.w;
           a.cache = 0;
-          a.xpos = {AT(c.geom_xpos, 3 * g1), AT(c.geom_xpos, 3 * g1 + 1), AT(c.geom_xpos, 3 * g1 + 2)};
-          for (int k = 0; k < 9; k++) a.R.a[k] = AT(c.geom_xmat, 9 * g1 + k);
+          if (f1) {
+            a.xpos = {f1[0], f1[1], f1[2]};
+            for (int k = 0; k < 9; k++) a.R.a[k] = f1[3 + k];
+          } else {
+            a.xpos = {AT(c.geom_xpos, 3 * g1), AT(c.geom_xpos, 3 * g1 + 1), AT(c.geom_xpos, 3 * g1 + 2)};
+            for (int k = 0; k < 9; k++) a.R.a[k] = AT(c.geom_xmat, 9 * g1 + k);
+          }
           a.margin = 0.5 * margin; b.margin = 0.5 * margin;
           mpr_begin(M, a.xpos, b.xpos);
         }

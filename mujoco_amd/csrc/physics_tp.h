@@ -803,7 +803,12 @@ __device__ __forceinline__ void tp_collide_prep(const DevModel& m, const TpModel
       s[0] = px; s[1] = py; s[2] = pz;
 #pragma unroll
       for (int k = 0; k < 9; k++) s[3 + k] = R.a[k];
-      if (env_ok) {
+      if (env_ok && cd.gframe) {  // one record per geom for the persistent narrowphase (the lanes' records are adjacent)
+        double* fr = cd.gframe + ((size_t)e * cm.ngeom + g) * 12;
+        fr[0] = px; fr[1] = py; fr[2] = pz;
+#pragma unroll
+        for (int k = 0; k < 9; k++) fr[3 + k] = R.a[k];
+      } else if (env_ok) {
         AT(cd.geom_xpos, 3 * g) = px; AT(cd.geom_xpos, 3 * g + 1) = py; AT(cd.geom_xpos, 3 * g + 2) = pz;
 #pragma unroll
         for (int k = 0; k < 9; k++) AT(cd.geom_xmat, 9 * g + k) = R.a[k];
