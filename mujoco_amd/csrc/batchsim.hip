@@ -1068,8 +1068,9 @@ extern "C" int bs_sim_create(const bs_model* const* models, int n_models, const 
     // dense Hessian (43 KB per environment) are allocated by ensure_serial_contact() only when the
     // serial dynamics kernel is going to run
     const size_t mc = (size_t)s->cm.maxcand, mk = (size_t)s->cm.maxcon;
-    const size_t drows = mc * 7 + mk * 13;
-    const size_t irows = 1 + mc * 2 + 1 + mk + 1 + mk;
+    const size_t drows = mc * 8 + mk * 13;  // candidates: 7 double rows + pair | hit as two int rows in one more: 64 bytes per slot,
+                                            // contiguous, so that the same memory can hold CandRec[E][maxcand] (ColData::crec)
+    const size_t irows = 1 + 1 + mk + 1 + mk;
     const size_t nstat = BS_STAT_CON + BS_NSUB;                        // counters (8 bytes each)
     const size_t nitems = mc * ((size_t)E + 4 * 2 * BS_NSUB);         // narrowphase work list, 4 ranges at most
     const size_t bytes = drows * E * sizeof(double) + irows * E * sizeof(int) + 16 + nstat * 8 + nitems * sizeof(int);
@@ -1086,10 +1087,11 @@ extern "C" int bs_sim_create(const bs_model* const* models, int n_models, const 
     ColData& c = s->cd;
     ConData& k = s->kd;
     c.cand_dist = take(mc); c.cand_pos = take(3 * mc); c.cand_nrm = take(3 * mc);
+    c.cand_pair = (int*)take(mc); c.cand_hit = c.cand_pair + mc * (size_t)E;
     c.con_dist = take(mk); c.con_pos = take(3 * mk); c.con_frame = take(9 * mk);
     int* ip = (int*)dp;
     auto takei = [&](size_t rows_) { int* q = ip; ip += rows_ * (size_t)E; return q; };
-    c.ncand = takei(1); c.cand_pair = takei(mc); c.cand_hit = takei(mc);
+    c.ncand = takei(1);
     c.ncon = takei(1); c.con_pair = takei(mk);
     k.ncrow = takei(1); k.con_efc = takei(mk);
     c.stat = (unsigned long long*)(((uintptr_t)ip + 7) & ~(uintptr_t)7);
@@ -1110,6 +1112,9 @@ extern "C" int bs_sim_create(const bs_model* const* models, int n_models, const 
       }
       HIPCHK_S(hipMemset(s->gframe, 0, gbytes));
       c.gframe = (double*)s->gframe;
+      // candidates as 64-byte records in the memory of the five [row][E] candidate arrays (the same size: 7 doubles + 2 ints per slot)
+      static_assert(sizeof(CandRec) == 64, "CandRec is one cache line");
+      c.crec = (CandRec*)c.cand_dist;
     }
   } else {
     s->fields[BS_F_NCON] = {d.nefc, 0, true};  // zero rows: no contacts in this sim

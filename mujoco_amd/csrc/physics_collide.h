@@ -86,6 +86,10 @@ inline void bin_dir(int bin, double* d) {
   else { d[0] = u; d[1] = v; d[2] = s; }
 }
 
+// a candidate as ONE 64-byte record, [E][maxcand] (tree-parallel path with the persistent narrowphase): the
+// broadphase writes `pair`, the narrowphase the rest, k_tpc's compaction reads it — one cache line per candidate
+// where the [row][E] arrays (the layout of the one-environment-per-lane kernels) touch nine
+struct CandRec { int pair, hit; double dist, pos[3], nrm[3]; };
 struct ColData {
   // geom frames (the sim's derived buffers)
   double *geom_xpos, *geom_xmat;
@@ -95,6 +99,7 @@ struct ColData {
   double *gframe;
   // candidates [maxcand][E]
   int *ncand, *cand_pair, *cand_hit;
+  CandRec *crec;  // non-null: candidates live here instead of cand_pair / cand_hit / cand_dist / cand_pos / cand_nrm
   // narrowphase work list of the tree-parallel path: (env - env0) << 8 | candidate slot.  The
   // broadphase blocks of a range append to BS_NSUB sub-lists (block index modulo BS_NSUB, so the
   // append counters stat[BS_STAT_ITEMS + range * BS_NSUB + sub] are not one hot address); sub-list
@@ -827,7 +832,7 @@ __device__ inline void col_narrow_persistent(const ColModel& cm, const DevData& 
         }
         const int it = items[lo * subcap + (i - pre[lo])];
         e = d.env0 + (it >> 8); slot = it & 255;
-        const int p = AT(c.cand_pair, slot) & BS_PAIR_MASK;
+        const int p = (c.crec ? c.crec[(size_t)e * cm.maxcand + slot].pair : AT(c.cand_pair, slot)) & BS_PAIR_MASK;
         const int4 r0 = *(const int4*)(cm.pair_np + 8 * p), r1 = *(const int4*)(cm.pair_np + 8 * p + 4);
         const int g1 = r0.x & 0xffff, g2 = r0.y;
         plane = (r0.x >> 16) != 0;
@@ -894,11 +899,21 @@ __device__ inline void col_narrow_persistent(const ColModel& cm, const DevData& 
         if (fin) { acc[0] += 1; acc[1] += (unsigned)iters; }
       }
       if (fin) {
-        AT(c.cand_hit, slot) = hit ? 1 : 0;
-        if (hit) {
-          AT(c.cand_dist, slot) = dist;
-          AT(c.cand_pos, 3 * slot) = pos.x; AT(c.cand_pos, 3 * slot + 1) = pos.y; AT(c.cand_pos, 3 * slot + 2) = pos.z;
-          AT(c.cand_nrm, 3 * slot) = nrm.x; AT(c.cand_nrm, 3 * slot + 1) = nrm.y; AT(c.cand_nrm, 3 * slot + 2) = nrm.z;
+        if (c.crec) {
+          CandRec* cr = c.crec + (size_t)e * cm.maxcand + slot;
+          cr->hit = hit ? 1 : 0;
+          if (hit) {
+            cr->dist = dist;
+            cr->pos[0] = pos.x; cr->pos[1] = pos.y; cr->pos[2] = pos.z;
+            cr->nrm[0] = nrm.x; cr->nrm[1] = nrm.y; cr->nrm[2] = nrm.z;
+          }
+        } else {
+          AT(c.cand_hit, slot) = hit ? 1 : 0;
+          if (hit) {
+            AT(c.cand_dist, slot) = dist;
+            AT(c.cand_pos, 3 * slot) = pos.x; AT(c.cand_pos, 3 * slot + 1) = pos.y; AT(c.cand_pos, 3 * slot + 2) = pos.z;
+            AT(c.cand_nrm, 3 * slot) = nrm.x; AT(c.cand_nrm, 3 * slot + 1) = nrm.y; AT(c.cand_nrm, 3 * slot + 2) = nrm.z;
+          }
         }
         busy = false;
       }

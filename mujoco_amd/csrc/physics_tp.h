@@ -854,7 +854,10 @@ __device__ __forceinline__ void tp_collide_prep(const DevModel& m, const TpModel
     const int at = count + __popc(m1 & lower) + 2 * __popc(m2 & lower) + 8 * __popc(m8 & lower);
     if (env_ok)
       for (int q = 0; q < cnt; q++)
-        if (at + q < cm.maxcand) AT(cd.cand_pair, at + q) = p | (q << 24);
+        if (at + q < cm.maxcand) {
+          if (cd.crec) cd.crec[(size_t)e * cm.maxcand + at + q].pair = p | (q << 24);
+          else AT(cd.cand_pair, at + q) = p | (q << 24);
+        }
     count += __popc(m1) + 2 * __popc(m2) + 8 * __popc(m8);
   }
   if (l == 0 && env_ok) {
@@ -1286,14 +1289,17 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
         for (int s0 = 0; s0 < cm.maxcand; s0 += TP_LPE) {
           if (!__ballot(s0 < ncand)) break;
           const int sidx = s0 + l;
-          const bool hit = sidx < ncand && AT(cd.cand_hit, sidx) != 0;
+          const CandRec* cr = cd.crec ? cd.crec + (size_t)e * cm.maxcand + (sidx < ncand ? sidx : 0) : nullptr;
+          const bool hit = sidx < ncand && (cr ? cr->hit : AT(cd.cand_hit, sidx)) != 0;
           const unsigned bits = (unsigned)(__ballot(hit) >> base);
           const int n = count + __popc(bits & ((1u << l) - 1u));
           if (hit && n < cm.maxcon) {
-            const int pr = AT(cd.cand_pair, sidx) & BS_PAIR_MASK;
-            const double dist = AT(cd.cand_dist, sidx);
-            const V3 p = {AT(cd.cand_pos, 3 * sidx), AT(cd.cand_pos, 3 * sidx + 1), AT(cd.cand_pos, 3 * sidx + 2)};
-            const V3 x = normalized(V3{AT(cd.cand_nrm, 3 * sidx), AT(cd.cand_nrm, 3 * sidx + 1), AT(cd.cand_nrm, 3 * sidx + 2)});
+            const int pr = (cr ? cr->pair : AT(cd.cand_pair, sidx)) & BS_PAIR_MASK;
+            const double dist = cr ? cr->dist : AT(cd.cand_dist, sidx);
+            const V3 p = cr ? V3{cr->pos[0], cr->pos[1], cr->pos[2]}
+                            : V3{AT(cd.cand_pos, 3 * sidx), AT(cd.cand_pos, 3 * sidx + 1), AT(cd.cand_pos, 3 * sidx + 2)};
+            const V3 x = normalized(cr ? V3{cr->nrm[0], cr->nrm[1], cr->nrm[2]}
+                                       : V3{AT(cd.cand_nrm, 3 * sidx), AT(cd.cand_nrm, 3 * sidx + 1), AT(cd.cand_nrm, 3 * sidx + 2)});
             V3 y = {0, 0, 0};
             if (x.y < 0.5 && x.y > -0.5) y.y = 1;
             else y.z = 1;
