@@ -669,15 +669,17 @@ __device__ TP_HELPER_ATTR TpLs tp_ls_eval(TpRows r, TpSol s, double alpha, doubl
     else if (x >= r.rf) { q0 += -r.fl * (0.5 * r.rf - x); q1 += r.fl * s.vf; }
     else { q0 += 0.5 * r.Df * x * x; q1 += r.Df * x * s.vf; q2 += 0.5 * r.Df * s.vf * s.vf; }
   }
-  {
-    const double x = s.jl0 + alpha * s.vl0, xm = fmin(x, 0.0);
-    q0 += 0.5 * r.Dl0 * xm * xm; q1 += r.Dl0 * xm * s.vl0;
-    if (x < 0) q2 += 0.5 * r.Dl0 * s.vl0 * s.vl0;
-  }
-  {
-    const double x = s.jl1 + alpha * s.vl1, xm = fmin(x, 0.0);
-    q0 += 0.5 * r.Dl1 * xm * xm; q1 += r.Dl1 * xm * s.vl1;
-    if (x < 0) q2 += 0.5 * r.Dl1 * s.vl1 * s.vl1;
+  if (__ballot(r.Dl0 != 0 || r.Dl1 != 0)) {  // wave-uniform: most steps have no joint inside a limit's margin
+    {
+      const double x = s.jl0 + alpha * s.vl0, xm = fmin(x, 0.0);
+      q0 += 0.5 * r.Dl0 * xm * xm; q1 += r.Dl0 * xm * s.vl0;
+      if (x < 0) q2 += 0.5 * r.Dl0 * s.vl0 * s.vl0;
+    }
+    {
+      const double x = s.jl1 + alpha * s.vl1, xm = fmin(x, 0.0);
+      q0 += 0.5 * r.Dl1 * xm * xm; q1 += r.Dl1 * xm * s.vl1;
+      if (x < 0) q2 += 0.5 * r.Dl1 * s.vl1 * s.vl1;
+    }
   }
   q0 = env_sum(q0); q1 = env_sum(q1); q2 = env_sum(q2);
   TpLs p;
