@@ -104,7 +104,7 @@ def _check_contact_samples(sim, m, q, c, ids, nsteps):
 
 
 def test_config2_65536_envs_contacts_default_path(hand_model):
-    """configs[2]: ground plane + mesh self-collision, 65 536 envs on the DEFAULT path (two-stream
+    """configs[2]: ground plane + mesh self-collision, 65 536 envs on the DEFAULT path (three-range
     split engaged by size, work-list narrowphase, tree-parallel dynamics), one step at the one-step
     tolerances (qacc 1e-8, contact sets exact), then 19 more."""
     import os
@@ -129,6 +129,30 @@ def test_config2_65536_envs_contacts_default_path(hand_model):
     assert st["contacts"] >= int(sim.data.ncon.sum())  # counters accumulate over the 20 steps
     _check_contact_samples(sim, m, q, c, ids, 20)
     print(f"config2: {ncon.mean():.2f} contacts / env, {st['narrow_pairs'] / (20 * E):.2f} narrowphase pairs / env-step")
+
+
+def test_small_batch_default_path_9000_envs(hand_model):
+    """The smallest batches that engage the three-range split (8192 envs and up), ragged: every
+    wavefront of the persistent narrowphase is down to its least share of items here (one per lane),
+    the last range is shorter than the others and ends inside a 64-environment block."""
+    import os
+    from mujoco_amd import workload
+    assert "BS_SPLIT" not in os.environ and "BS_NL_SHARE" not in os.environ
+    m = workload.with_ground_plane(hand_model, z=-0.05)
+    E = 9001
+    sim, q, v, c = _contact_run(m, E, 1240, 10)
+    chunk = (E // 3 + 63) // 64 * 64
+    ids = _samples(E, extra=(chunk - 1, chunk, 2 * chunk - 1, 2 * chunk, E - 1, E - 2, 8960, 8959))
+    sim.collision_stats(reset=True)
+    sim.step(1); sim.sync()
+    st = sim.collision_stats()
+    assert st["contacts"] == int(sim.data.ncon.sum())
+    assert int((sim.data.warning != 0).sum()) == 0
+    assert _check_contact_samples(sim, m, q, c, ids, 1) > 32
+    sim.step(9); sim.sync()
+    assert np.isfinite(sim.data.qpos.cpu().numpy()).all()
+    assert int((sim.data.warning != 0).sum()) == 0
+    _check_contact_samples(sim, m, q, c, ids, 10)
 
 
 def test_config4_per_gpu_share_131072_envs_with_obs_gather(hand_model):
