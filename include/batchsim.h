@@ -204,6 +204,19 @@ int bs_timed_steps(bs_sim *s, int n_steps, double *elapsed_ms);
  * reward of BASELINE.json configs[4].  `out_dev` is device memory of the sim's GPU with room for
  * n_envs * row_stride floats; row_stride >= nq + nv + 1. */
 int bs_pack_obs(bs_sim *s, float *out_dev, int64_t row_stride);
+/* The two ends of a control period for the learner glue, each ONE launch on the sim's stream (the reference has
+ * no environment code, src/Mujoco_XML.py:327-330; definitions in mujoco_amd/env.py).
+ * bs_env_pre: ctrl[u] = action[e * ld + u] clamped to actuator u's ctrlrange, for every environment e
+ * (action_dev: n_envs rows of ld >= nu doubles in device memory).
+ * bs_env_post, after bs_step, with the same action: reward[e] = -sum_u (qpos[joint of actuator u] - clamped action[u])^2; t[e] += 1;
+ * flags[e] = 1 (done: failed or t[e] >= episode_steps) | 2 (failed: mj_check* reset the environment, warning
+ * bits 0-2) | 4 (contact / candidate list overflowed, warning bit 3, cleared here); term_obs[e] = qpos | qvel as
+ * fp32 as the period left them; finished environments are reset (bs_reset's arithmetic, t[e] = 0) and obs[e] is
+ * what the next action is chosen from (= term_obs[e] for the others).  obs / term_obs: n_envs rows of
+ * row_stride >= nq + nv floats; t: int32[n_envs]; reward: float[n_envs]; flags: uint8[n_envs], all device memory. */
+int bs_env_pre(bs_sim *s, const double *action_dev, int64_t ld);
+int bs_env_post(bs_sim *s, const double *action_dev, int64_t ld, int32_t *t_dev, int episode_steps, float *obs_dev,
+                float *term_obs_dev, int64_t row_stride, float *reward_dev, uint8_t *flags_dev);
 
 #ifdef __cplusplus
 }

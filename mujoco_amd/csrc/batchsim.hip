@@ -1615,6 +1615,33 @@ extern "C" int bs_pack_obs(bs_sim* s, float* out_dev, int64_t row_stride) {
   return BS_OK;
 }
 
+extern "C" int bs_env_pre(bs_sim* s, const double* action_dev, int64_t ld) {
+  if (!s || !action_dev) return fail(BS_ERR_INVALID, "bs_env_pre: null argument");
+  NO_PARTS(s, "bs_env_pre");
+  if (ld < s->dm.nu) return fail(BS_ERR_INVALID, "bs_env_pre: ld %lld < nu = %d", (long long)ld, s->dm.nu);
+  HIPCHK(hipSetDevice(s->device));
+  bs_launch_env_pre(dim3((unsigned)((s->n_envs + 255) / 256)), s->stream, s->dm, s->dd, action_dev, (long)ld);
+  HIPCHK(hipGetLastError());
+  return BS_OK;
+}
+
+extern "C" int bs_env_post(bs_sim* s, const double* action_dev, int64_t ld, int32_t* t_dev, int episode_steps, float* obs_dev,
+                           float* term_obs_dev, int64_t row_stride, float* reward_dev, uint8_t* flags_dev) {
+  if (!s || !action_dev || !t_dev || !obs_dev || !term_obs_dev || !reward_dev || !flags_dev)
+    return fail(BS_ERR_INVALID, "bs_env_post: null argument");
+  NO_PARTS(s, "bs_env_post");
+  const int nq = s->fields[BS_F_QPOS].rows;
+  if (row_stride < nq + s->dm.nv)
+    return fail(BS_ERR_INVALID, "bs_env_post: row_stride %lld < nq + nv = %d", (long long)row_stride, nq + s->dm.nv);
+  if (episode_steps < 1) return fail(BS_ERR_INVALID, "bs_env_post: episode_steps must be >= 1");
+  if (ld < s->dm.nu) return fail(BS_ERR_INVALID, "bs_env_post: ld %lld < nu = %d", (long long)ld, s->dm.nu);
+  HIPCHK(hipSetDevice(s->device));
+  bs_launch_env_post(dim3((unsigned)((s->n_envs + 255) / 256)), s->stream, s->dm, s->dd, action_dev, (long)ld, t_dev,
+                     episode_steps, obs_dev, term_obs_dev, (long)row_stride, reward_dev, flags_dev, nq);
+  HIPCHK(hipGetLastError());
+  return BS_OK;
+}
+
 extern "C" int bs_timed_steps(bs_sim* s, int n_steps, double* elapsed_ms) {
   if (!s || !elapsed_ms) return fail(BS_ERR_INVALID, "bs_timed_steps: null argument");
   if (n_steps < 1) return fail(BS_ERR_INVALID, "bs_timed_steps: n_steps must be >= 1");

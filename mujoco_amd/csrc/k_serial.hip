@@ -128,7 +128,58 @@ __global__ __launch_bounds__(256) void k_pack_obs(DevModel m, DevData d, float* 
   o[nq + m.nv] = (float)(-r);
 }
 
+// ---- learner glue around bs_step (mujoco_amd/env.py::HandVecEnv.step), one lane per environment
+// before the steps: ctrl = action clamped to the actuators' ctrlrange (action: [n_envs][ld] doubles, row = environment)
+__global__ __launch_bounds__(256) void k_env_pre(DevModel m, DevData d, const double* action, long ld) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x, E = d.E;
+  if (e >= d.n_envs) return;
+  for (int u = 0; u < m.nu; u++) {
+    const double a = action[e * ld + u];
+    AT(d.ctrl, u) = fmin(fmax(a, m.actuator_ctrlrange[2 * u]), m.actuator_ctrlrange[2 * u + 1]);
+  }
+}
+// after the steps: reward, episode clock, done / failed / overflow flags, the observation of the finished
+// episodes (terminal), reset of the finished environments (k_reset's arithmetic), the observation to act on
+__global__ __launch_bounds__(256) void k_env_post(DevModel m, DevData d, const double* action, long ld, int* t, int episode_steps,
+                                                  float* obs, float* term_obs, long stride, float* reward, uint8_t* flags, int nq) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x, E = d.E;
+  if (e >= d.n_envs) return;
+  double r = 0;
+  for (int u = 0; u < m.nu; u++) {
+    // against the clamped ACTION, not ctrl: a mj_check* reset during the period has zeroed ctrl
+    const double a = fmin(fmax(action[e * ld + u], m.actuator_ctrlrange[2 * u]), m.actuator_ctrlrange[2 * u + 1]);
+    const double err = AT(d.qpos, m.jnt_qposadr[m.actuator_trnid[u]]) - a;
+    r += err * err;
+  }
+  reward[e] = (float)(-r);
+  const int w = AT(d.warning, 0), tt = t[e] + 1;
+  const bool failed = (w & 7) != 0, overflow = (w & 8) != 0, done = failed || tt >= episode_steps;
+  flags[e] = (uint8_t)((done ? 1 : 0) | (failed ? 2 : 0) | (overflow ? 4 : 0));
+  float* to = term_obs + e * stride;
+  float* o = obs + e * stride;
+  for (int i = 0; i < nq; i++) to[i] = (float)AT(d.qpos, i);
+  for (int i = 0; i < m.nv; i++) to[nq + i] = (float)AT(d.qvel, i);
+  if (done) {
+    env_reset(m, d, e);
+    AT(d.warning, 0) = 0;
+    t[e] = 0;
+    for (int i = 0; i < nq; i++) o[i] = (float)AT(d.qpos, i);
+    for (int i = 0; i < m.nv; i++) o[nq + i] = 0.0f;
+  } else {
+    AT(d.warning, 0) = w & 7;
+    t[e] = tt;
+    for (int i = 0; i < nq + m.nv; i++) o[i] = to[i];
+  }
+}
+
 // ---- launchers
+void bs_launch_env_pre(dim3 g, hipStream_t st, const DevModel& m, const DevData& d, const double* action, long ld) {
+  hipLaunchKernelGGL(k_env_pre, g, dim3(256), 0, st, m, d, action, ld);
+}
+void bs_launch_env_post(dim3 g, hipStream_t st, const DevModel& m, const DevData& d, const double* action, long ld, int* t,
+                        int episode_steps, float* obs, float* term_obs, long stride, float* reward, uint8_t* flags, int nq) {
+  hipLaunchKernelGGL(k_env_post, g, dim3(256), 0, st, m, d, action, ld, t, episode_steps, obs, term_obs, stride, reward, flags, nq);
+}
 void bs_launch_step(dim3 g, hipStream_t st, const DevModel& m, const DevData& d, int nsteps) {
   hipLaunchKernelGGL(k_step, g, dim3(BS_BLOCK), 0, st, m, d, nsteps);
 }

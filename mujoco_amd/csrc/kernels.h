@@ -35,6 +35,9 @@ void bs_launch_rk4_advance(dim3 g, hipStream_t st, const DevModel& m, const DevD
 void bs_launch_frames(dim3 g, hipStream_t st, const DevModel& m, const DevData& d, double* xmat, double* gpos,
                       double* gmat);
 void bs_launch_pack_obs(dim3 g, hipStream_t st, const DevModel& m, const DevData& d, float* out, long stride, int nq);
+void bs_launch_env_pre(dim3 g, hipStream_t st, const DevModel& m, const DevData& d, const double* action, long ld);
+void bs_launch_env_post(dim3 g, hipStream_t st, const DevModel& m, const DevData& d, const double* action, long ld, int* t,
+                        int episode_steps, float* obs, float* term_obs, long stride, float* reward, uint8_t* flags, int nq);
 void bs_launch_c_pos(dim3 g, hipStream_t st, const DevModel& m, const DevData& d, const ColData& c, int check);
 void bs_launch_c_broad(dim3 g, hipStream_t st, const ColModel& cm, const DevData& d, const ColData& c);
 void bs_launch_c_dyn(dim3 g, size_t lds, hipStream_t st, const DevModel& m, const ColModel& cm, const DevData& d,

@@ -14,8 +14,11 @@ everything here is this build's definition, kept deliberately small:
 With `world > 1` (one process per GPU) `step` also returns the all-gathered `[world * n_envs, ...]`
 observation / reward of every rank for a centralised learner (`mujoco_amd.dist`, RCCL).
 """
+import ctypes as C
+
 import torch
 
+from . import _abi
 from . import dist as bdist
 
 
@@ -63,7 +66,34 @@ class HandVecEnv:
     def step(self, action):
         """action: `[n_envs, nu]` device tensor.  Returns obs, reward, done, info; finished
         environments are already reset in the returned observation (`info["terminal_obs"]` holds
-        the last observation of the finished episodes)."""
+        the last observation of the finished episodes).  Without reset noise a control period is three
+        launches — bs_env_pre, bs_step, bs_env_post — instead of some twenty torch kernels (at 4096
+        contact-free environments and frame_skip 10 those were half of the period)."""
+        if self.reset_noise > 0:
+            return self._step_torch(action)
+        L, h = _abi.lib(), self.sim._h
+        a = action.to(torch.float64).contiguous()
+        dev = a.device  # fresh outputs every period (the caching allocator hands them out without a device call)
+        obs = torch.empty((self.n_envs, self.obs_dim), dtype=torch.float32, device=dev)
+        term = torch.empty((self.n_envs, self.obs_dim), dtype=torch.float32, device=dev)
+        reward = torch.empty(self.n_envs, dtype=torch.float32, device=dev)
+        flags = torch.empty(self.n_envs, dtype=torch.uint8, device=dev)
+        _abi.check(L.bs_env_pre(h, C.c_void_p(a.data_ptr()), a.shape[1]))
+        self.sim.step(self.frame_skip)
+        _abi.check(L.bs_env_post(h, C.c_void_p(a.data_ptr()), a.shape[1], C.c_void_p(self.t.data_ptr()), self.episode_steps,
+                                 C.c_void_p(obs.data_ptr()), C.c_void_p(term.data_ptr()), self.obs_dim,
+                                 C.c_void_p(reward.data_ptr()), C.c_void_p(flags.data_ptr())))
+        self._keep = a  # alive until the kernels that read it have run
+        done, failed, overflow = (flags & 1) != 0, (flags & 2) != 0, (flags & 4) != 0
+        info = {"terminal_obs": term, "failed": failed, "contact_overflow": overflow}
+        if self.world > 1:
+            packed = torch.cat([obs, reward.unsqueeze(1)], dim=1).contiguous()
+            info["gathered"] = bdist.all_gather_packed(packed, self.world, self.group, self._gathered)
+        return obs, reward, done, info
+
+    def _step_torch(self, action):
+        """The same control period written with torch operations on the zero-copy views (the path with
+        reset noise, and the reference the fused kernels are tested against)."""
         d = self.sim.data
         a = torch.minimum(torch.maximum(action.to(d.ctrl.dtype), self.ctrl_lo), self.ctrl_hi)
         d.ctrl.copy_(a)

@@ -1005,3 +1005,38 @@ def test_pgs_with_contacts_tree_parallel(hand_model, plane, monkeypatch):
         assert abs(int(a[1][e]) - s.solver_iter) <= 1 and a[2][e] == s.ncon
         s.step(n - 1)
         assert np.abs(a[4][e] - s.qpos).max() < 1e-7 and np.abs(a[5][e] - s.qvel).max() < 1e-5, e
+
+
+def test_vec_env_fused_period_matches_torch_path(hand_model):
+    """HandVecEnv.step: the fused control period (bs_env_pre, bs_step, bs_env_post) against the same period
+    written with torch operations — observations, rewards, done / failed / overflow flags, terminal
+    observations, episode clocks and the state left behind, over episode ends and a mj_check* failure."""
+    import torch
+    from mujoco_amd import BatchSim, workload
+    from mujoco_amd.env import HandVecEnv
+    for m in (workload.contact_free(hand_model), workload.with_ground_plane(hand_model, z=-0.05)):
+        E = 96
+        sims = [BatchSim(m, n_envs=E) for _ in range(2)]
+        envs = [HandVecEnv(s, frame_skip=5, episode_steps=3) for s in sims]
+        o0, o1 = envs[0].reset(), envs[1].reset()
+        assert torch.equal(o0, o1)
+        g = torch.Generator(device=o0.device); g.manual_seed(11)
+        for period in range(8):
+            a = torch.rand((E, m.nu), generator=g, device=o0.device, dtype=torch.float64) * 3.0 - 1.0   # beyond ctrlrange too
+            if period == 4:  # poison one environment of both sims: mj_checkPos resets it inside the period
+                for s in sims:
+                    s.data.qpos[7, 2] = float("nan")
+            of, rf, df, inf_ = envs[0].step(a)
+            ot, rt, dt, int_ = envs[1]._step_torch(a)
+            assert torch.equal(df, dt), period
+            assert torch.equal(inf_["failed"], int_["failed"]) and torch.equal(inf_["contact_overflow"], int_["contact_overflow"])
+            if period == 4:
+                assert bool(inf_["failed"][7]) and bool(df[7])
+            assert torch.equal(of, ot), period
+            assert torch.equal(inf_["terminal_obs"], int_["terminal_obs"]), period
+            assert torch.allclose(rf, rt, rtol=1e-6, atol=1e-9), period
+            assert torch.equal(envs[0].t, envs[1].t)
+            for f in ("qpos", "qvel", "ctrl", "qacc_warmstart", "time", "warning"):
+                assert torch.equal(getattr(sims[0].data, f), getattr(sims[1].data, f)), (period, f)
+        for s in sims:
+            s.close()
