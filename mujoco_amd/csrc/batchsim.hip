@@ -10,6 +10,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "kernels.h"
@@ -591,19 +592,34 @@ static int model_image(bs_model* m, int device, const DeviceImage** out) {
   PUT_CI(hull_adj, s.hull_adj, s.nhulladj);
   // climb warm-start table: exhaustive support vertex for the centre direction of every bin
   std::vector<int32_t> hstart((size_t)(s.nmesh > 0 ? s.nmesh : 1) * BS_NSTART, 0);
-  for (int me = 0; me < s.nmesh; me++) {
-    const double* V = s.hull_vert + 3 * (size_t)s.mesh_vertadr[me];
-    for (int bin = 0; bin < BS_NSTART; bin++) {
-      double dd[3];
-      bin_dir(bin, dd);
-      int best = 0;
-      double bv = -1e300;
-      for (int v = 0; v < s.mesh_vertnum[me]; v++) {
-        const double val = V[3 * v] * dd[0] + V[3 * v + 1] * dd[1] + V[3 * v + 2] * dd[2];
-        if (val > bv) { bv = val; best = v; }
+  {
+    // exhaustive (lowest index wins a tie), 6 x 64 x 64 bins per hull: a few hundred million multiply-adds
+    // per model, spread over up to eight host threads
+    auto fill = [&](int me, int b0, int b1) {
+      const double* V = s.hull_vert + 3 * (size_t)s.mesh_vertadr[me];
+      for (int bin = b0; bin < b1; bin++) {
+        double dd[3];
+        bin_dir(bin, dd);
+        int best = 0;
+        double bv = -1e300;
+        for (int v = 0; v < s.mesh_vertnum[me]; v++) {
+          const double val = V[3 * v] * dd[0] + V[3 * v + 1] * dd[1] + V[3 * v + 2] * dd[2];
+          if (val > bv) { bv = val; best = v; }
+        }
+        hstart[(size_t)me * BS_NSTART + bin] = best;
       }
-      hstart[(size_t)me * BS_NSTART + bin] = best;
-    }
+    };
+    unsigned nt = std::thread::hardware_concurrency();
+    nt = nt < 1 ? 1 : nt > 8 ? 8 : nt;
+    std::vector<std::thread> pool;
+    for (unsigned k = 0; k < nt; k++)
+      pool.emplace_back([&, k]() {
+        for (int me = 0; me < s.nmesh; me++) {
+          const int per = (BS_NSTART + (int)nt - 1) / (int)nt, b0 = (int)k * per, b1 = b0 + per < BS_NSTART ? b0 + per : BS_NSTART;
+          if (b0 < b1) fill(me, b0, b1);
+        }
+      });
+    for (auto& th : pool) th.join();
   }
   PUT_CI(hull_start, hstart.data(), hstart.size());
   std::vector<double> start4(hstart.size() * 4, 0.0);
