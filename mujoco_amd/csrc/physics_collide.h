@@ -430,16 +430,16 @@ __device__ __forceinline__ int mpr_step(MprState& M, const Spt& sfull, const V3&
       it = 0;
       check_refine = true;
     }
-  } else if (state == 3) {  // refinement
+  } else {
+    // refinement (state 3) and penetration (state 4: push the portal to the surface) share their arithmetic — the
+    // tolerance test, the portal expansion, the new portal direction — so the lanes of a wavefront that are in
+    // either state run ONE copy of it together instead of two copies one after the other
     iters++;
-    const double y = dot(s.v, d);
-    if (!(c_is_zero(y) || y > 0) || reach_tol(P, s, d, tol)) return 2;
-    expand_portal(P, p0, s);
-    it++;
-    check_refine = true;
-  } else {  // penetration: push the portal to the surface
-    iters++;
-    if (reach_tol(P, s, d, tol) || it > maxit) {
+    const bool rt = reach_tol(P, s, d, tol);
+    if (state == 3) {
+      const double y = dot(s.v, d);
+      if (!(c_is_zero(y) || y > 0) || rt) return 2;
+    } else if (rt || it > maxit) {
       V3 w;
       depth = sqrt(origin_tri_dist2(P[1].v, P[2].v, P[3].v, w));
       dir = c_is_zero(depth) ? origin : normalized(w);
@@ -469,7 +469,14 @@ __device__ __forceinline__ int mpr_step(MprState& M, const Spt& sfull, const V3&
     }
     expand_portal(P, p0, s);
     it++;
-    d = portal_dir(P);
+    if (state == 3) {
+      if (it > maxit + 1) return 2;
+      d = portal_dir(P);
+      const double x = dot(d, P[1].v);
+      if (c_is_zero(x) || x > 0) { it = 0; state = 4; }  // portal encloses the origin ray
+    } else {
+      d = portal_dir(P);
+    }
   }
 
   if (check_refine) {
