@@ -815,7 +815,7 @@ static void launch_narrow(bs_sim* s, const DevData& dd, hipStream_t st) {
 }
 // one forward pass (mode 1) or step (mode 0) with contacts through the tree-parallel kernels, for
 // the environments [dd.env0, dd.n_envs) on stream st
-static void launch_tpc_pass(bs_sim* s, const DevData& dd, hipStream_t st, int mode, int dump) {
+static void launch_tpc_pass(bs_sim* s, const DevData& dd, hipStream_t st, int mode, int dump, bool full = false) {
 #ifdef TPC_CUTS
   if (const char* e = getenv("BS_CUT")) dump |= (atoi(e) + 1) << 8;
 #endif
@@ -837,7 +837,8 @@ static void launch_tpc_pass(bs_sim* s, const DevData& dd, hipStream_t st, int mo
     return;
   }
   const size_t lds = (size_t)(2 * ntri + 2 * TP_LPE * TPC_SLOT + 2 * TP_LPE * 3) * sizeof(double);
-  (s->dm.solver == 1 ? bs_launch_tpc_cg : bs_launch_tpc)(g, lds, st, s->dm, s->tp, dd, s->cm, s->cd, mode, dump);
+  auto* launch = s->dm.solver == 1 ? (full ? bs_launch_tpc_full_cg : bs_launch_tpc_cg) : (full ? bs_launch_tpc_full : bs_launch_tpc);
+  launch(g, lds, st, s->dm, s->tp, dd, s->cm, s->cd, mode, dump);
 }
 // check: mj_checkPos/Vel first; integrate: mj_step (Euler) rather than mj_forward; fast: let the
 // tree-parallel kernels run a forward pass too (they leave the position-stage intermediates of
@@ -1278,8 +1279,12 @@ extern "C" int bs_forward(bs_sim* s) {
     }
     return BS_OK;
   }
-  if (s->contacts) {
-    const int rc = ensure_serial_contact(s);  // bs_forward writes every intermediate: serial pipeline
+  if (s->contacts && s->use_tpc && s->dm.solver != 0) {
+    // every intermediate written by the tree-parallel kernels too (k_tpc_full / k_tpc_full_cg, round 2): no
+    // serial pipeline, none of its 43 KB per environment of solver buffers
+    launch_tpc_pass(s, s->dd, s->stream, 1, 2, true);
+  } else if (s->contacts) {
+    const int rc = ensure_serial_contact(s);  // PGS with contacts, ineligible models: serial pipeline
     if (rc) return rc;
     launch_contact_pass(s, 0, 0);
   } else if (s->use_tp) {

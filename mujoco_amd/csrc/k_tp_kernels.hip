@@ -21,14 +21,15 @@
 
 // contacts: candidates from k_tp_col + the narrowphase kernel, one step per launch.  Dynamic LDS:
 // packed Hessians for nbody rows (2 envs), then contact slots, then the U staging rows
-#define TPC_KERNEL(name, CG_, PGS_)                                                                                   \
+#define TPC_KERNEL(name, CG_, PGS_) TPC_KERNEL_F(name, false, CG_, PGS_)
+#define TPC_KERNEL_F(name, FULL_, CG_, PGS_)                                                                                   \
   __global__ __launch_bounds__(64, TPC_OCC) void k_##name(DevModel m, TpModel t, DevData d, ColModel cm, ColData cd,  \
                                                           int mode, int dump) {                                      \
     __shared__ int tbl[TPL_TOTAL * 64];                                                                               \
     extern __shared__ double tpc_dyn[];                                                                               \
     const int ntri = m.nbody * (m.nbody + 1) / 2;                                                                     \
     const TpShared sh = {tbl, tpc_dyn, tpc_dyn + 2 * ntri, tpc_dyn + 2 * ntri + 2 * TP_LPE * TPC_SLOT, nullptr, nullptr}; \
-    tp_run<true, false, false, CG_, PGS_>(m, t, d, 1, mode, dump, sh, cm, cd);                                        \
+    tp_run<true, FULL_, false, CG_, PGS_>(m, t, d, 1, mode, dump, sh, cm, cd);                                        \
   }                                                                                                                   \
   void bs_launch_##name(BS_TPC_ARGS) { hipLaunchKernelGGL(k_##name, g, dim3(64), lds, st, m, t, d, cm, cd, mode, dump); }
 
@@ -64,6 +65,11 @@ void bs_launch_tp_col(dim3 g, size_t lds, hipStream_t st, const DevModel& m, con
 TPC_KERNEL(tpc, false, false)
 #elif defined(TPK_tpc_cg)
 TPC_KERNEL(tpc_cg, true, false)
+#elif defined(TPK_tpc_full)
+// bs_forward with contacts: every intermediate written (the FULL dump of k_tp_full + the contact list)
+TPC_KERNEL_F(tpc_full, true, false, false)
+#elif defined(TPK_tpc_full_cg)
+TPC_KERNEL_F(tpc_full_cg, true, true, false)
 #elif defined(TPK_tpc_pgs)
 // contacts, PGS: no Hessian; dynamic LDS = contact slots (wider: aref, forces, B per contact), the U staging rows,
 // then M^-1 of the two environments

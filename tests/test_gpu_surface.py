@@ -275,3 +275,61 @@ def test_kernel_path_is_reported_and_fallback_warns(hand_model, monkeypatch):
     assert not fast and "BS_KERNEL=serial" in path and "k_step" in path
     sim.close()
     monkeypatch.delenv("BS_KERNEL")
+
+
+@pytest.mark.parametrize("solver", ["newton", "cg"])
+def test_forward_with_contacts_writes_every_intermediate_on_tp_kernels(hand_model, solver):
+    """bs_forward of a contact model on the tree-parallel path (k_tp_col, narrowphase, k_tpc_full[_cg]): the
+    intermediates a mj_forward leaves behind — poses, cinert / cdof / cvel, the fixed efc rows, forces, qacc and
+    the contact list — against the oracle, and the same call again after steps."""
+    import torch
+    from mujoco_amd import BatchSim, workload
+    from oracle import OracleSim
+    m = workload.with_ground_plane(hand_model, z=-0.05)
+    if solver == "cg":
+        import copy
+        from mujoco_amd.model import SOL_CG
+        m = copy.deepcopy(m)
+        m.opt_solver = SOL_CG
+    E = 70
+    q, v = workload.config2_state(m, E, seed=31)
+    v = np.random.default_rng(5).normal(size=v.shape) * 0.3
+    c = workload.config2_ctrl(m, E, seed=31)
+    sim = BatchSim(m, n_envs=E)
+    fast, path = sim.kernel_path()
+    assert fast and "k_tpc" in path
+    sim.data.qpos.copy_(torch.as_tensor(q)); sim.data.qvel.copy_(torch.as_tensor(v)); sim.data.ctrl.copy_(torch.as_tensor(c))
+    sim.forward(); sim.sync()
+    fields = ("xpos", "xquat", "rootcom", "cinert", "cdof", "cvel", "xipos", "xanchor", "xaxis", "efc_D", "efc_aref",
+              "qfrc_constraint", "nefc", "qfrc_bias", "qfrc_passive", "qfrc_actuator", "qfrc_smooth", "qacc_smooth", "qacc", "ncon")
+    got = {f: getattr(sim.data, f).cpu().numpy() for f in fields}
+    root = int(m.body_rootid[m.nbody - 1])
+    ncon_tot = 0
+    for e in range(0, E, 6):
+        s = OracleSim(m)
+        s.qpos[:] = q[e]; s.qvel[:] = v[e]; s.ctrl[:] = c[e]
+        s.forward()
+        assert np.abs(got["xpos"][e].reshape(-1) - np.asarray(s.xpos).reshape(-1)).max() <= 1e-12
+        assert np.abs(got["rootcom"][e].reshape(-1, 3)[root] - s.subtree_com[root]).max() <= 1e-12
+        for f, tol in (("cinert", 1e-12), ("cdof", 1e-12), ("cvel", 1e-11), ("xipos", 1e-12), ("xanchor", 1e-12), ("xaxis", 1e-12)):
+            ref = np.asarray(getattr(s, f)).reshape(-1)
+            assert np.abs(got[f][e].reshape(-1) - ref).max() <= tol * max(1.0, np.abs(ref).max()), (f, e)
+        for f, tol in (("qfrc_bias", 1e-11), ("qfrc_passive", 1e-12), ("qfrc_actuator", 1e-12), ("qfrc_smooth", 1e-11), ("qacc_smooth", 1e-9)):
+            ref = np.asarray(getattr(s, f))
+            assert np.abs(got[f][e] - ref).max() <= tol * max(1.0, np.abs(ref).max()), (f, e)
+        assert got["nefc"][e] == s.nefc and got["ncon"][e] == s.ncon
+        ncon_tot += s.ncon
+        assert sorted((a, b) for a, b, _ in sim.data.contacts(e)) == sorted((cc["geom1"], cc["geom2"]) for cc in s.contacts())
+        rows = _efc_row_map(m, s)
+        fixed = rows >= 0
+        for f, tol in (("efc_D", 1e-12), ("efc_aref", 1e-10)):
+            ref = s.efc(f[4:])[fixed]
+            assert np.abs(got[f][e][rows[fixed]] - ref).max() <= tol * max(1.0, np.abs(ref).max()), (f, e)
+        tol = 1e-8 if solver == "newton" else 1e-6
+        assert np.abs(got["qacc"][e] - s.qacc).max() <= tol * max(1.0, np.abs(s.qacc).max()), e
+        assert np.abs(got["qfrc_constraint"][e] - s.qfrc_constraint).max() <= tol * max(1.0, np.abs(s.qfrc_constraint).max()), e
+    assert ncon_tot > 10
+    # forward again after steps: same call, state advanced
+    sim.step(5); sim.forward(); sim.sync()
+    assert np.isfinite(sim.data.qacc.cpu().numpy()).all() and np.isfinite(sim.data.cinert.cpu().numpy()).all()
+    sim.close()

@@ -169,7 +169,8 @@ def test_primitive_pairs_device_vs_oracle(kernel, monkeypatch):
             # to the tolerance of the algorithm, everything else (closed forms, polyhedra) to rounding
             loose = by_mpr(t1, t2) and (t1 in curved or t2 in curved)
             loose_env |= loose
-            td, tp, tf = (5e-5, 5e-4, 5e-3) if loose else (1e-9, 1e-8, 1e-7)
+            # (the normal of a curved contact found to 1e-6 in depth is only defined to sqrt(2e-6 / radius) ~ 1e-2 rad)
+            td, tp, tf = (5e-5, 5e-4, 2e-2) if loose else (1e-9, 1e-8, 1e-7)
             assert abs(a.dist - b["dist"]) < td and np.abs(a.pos - b["pos"]).max() < tp, (e, t1, t2)
             assert np.abs(a.frame - b["frame"]).max() < tf, (e, t1, t2)
         assert ncon[e] == s.ncon
