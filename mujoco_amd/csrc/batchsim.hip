@@ -818,6 +818,8 @@ static void launch_narrow(bs_sim* s, const DevData& dd, hipStream_t st) {
 static void launch_tpc_pass(bs_sim* s, const DevData& dd, hipStream_t st, int mode, int dump, bool full = false) {
 #ifdef TPC_CUTS
   if (const char* e = getenv("BS_CUT")) dump |= (atoi(e) + 1) << 8;
+  extern void bs_set_colcut(int);
+  if (const char* e = getenv("BS_COLCUT")) bs_set_colcut(atoi(e));
 #endif
   const dim3 g((unsigned)((dd.n_envs - dd.env0 + 1) / 2));
   const size_t lds_col = (size_t)2 * s->cm.ngeom * TPG_SLOT * sizeof(double);

@@ -53,6 +53,18 @@ TP_KERNEL(tp_full_cg, false, true, false, true, false, false, false)
 TP_KERNEL(tp_full_pgs, false, true, false, false, true, false, true)
 #elif defined(TPK_tp_col)
 // kinematics + geom frames + broadphase, tree-parallel layout (physics_tp.h::tp_collide_prep)
+#ifdef TPC_CUTS  // developer build: the kernel returns at section BS_COLCUT
+static int g_colcut = -1;
+void bs_set_colcut(int c) { g_colcut = c; }
+__global__ __launch_bounds__(64) void k_tp_col(DevModel m, TpModel t, DevData d, ColModel cm, ColData cd, int colcut) {
+  extern __shared__ double tpg_dyn[];
+  tp_collide_prep(m, t, d, cm, cd, tpg_dyn, colcut);
+}
+void bs_launch_tp_col(dim3 g, size_t lds, hipStream_t st, const DevModel& m, const TpModel& t, const DevData& d,
+                      const ColModel& cm, const ColData& cd) {
+  hipLaunchKernelGGL(k_tp_col, g, dim3(64), lds, st, m, t, d, cm, cd, g_colcut);
+}
+#else
 __global__ __launch_bounds__(64) void k_tp_col(DevModel m, TpModel t, DevData d, ColModel cm, ColData cd) {
   extern __shared__ double tpg_dyn[];  // geom frames of the two environments
   tp_collide_prep(m, t, d, cm, cd, tpg_dyn);
@@ -61,6 +73,7 @@ void bs_launch_tp_col(dim3 g, size_t lds, hipStream_t st, const DevModel& m, con
                       const ColModel& cm, const ColData& cd) {
   hipLaunchKernelGGL(k_tp_col, g, dim3(64), lds, st, m, t, d, cm, cd);
 }
+#endif
 #elif defined(TPK_tpc)
 TPC_KERNEL(tpc, false, false)
 #elif defined(TPK_tpc_cg)

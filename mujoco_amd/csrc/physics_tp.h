@@ -747,8 +747,14 @@ __device__ __forceinline__ double tp_line_search(const DevModel& m, const TpRows
 // per wavefront.  Replaces k_c_pos + k_c_broad when k_tpc runs the dynamics; a state that fails
 // mj_checkPos / mj_checkVel is treated as reset (k_tpc performs the reset itself).
 #define TPG_SLOT 13  // doubles per geom frame in LDS: position, matrix (odd stride)
+#ifdef TPC_CUTS
+#define COL_T(i) { if (colcut == i) return; }
+#else
+#define COL_T(i)
+#endif
 __device__ __forceinline__ void tp_collide_prep(const DevModel& m, const TpModel& t, const DevData& d,
-                                                const ColModel& cm, const ColData& cd, double* gfr) {
+                                                const ColModel& cm, const ColData& cd, double* gfr, int colcut = -1) {
+  COL_T(0)
   const int tid = threadIdx.x;
   const int l = tid & (TP_LPE - 1), base = tid & ~(TP_LPE - 1);
   long env = d.env0 + (long)blockIdx.x * (64 / TP_LPE) + (tid / TP_LPE);
@@ -787,7 +793,9 @@ __device__ __forceinline__ void tp_collide_prep(const DevModel& m, const TpModel
   }
   V3 pos;
   Q4 quat;
+  COL_T(1)
   tp_chain_pose(pos, quat, lp, lq, par_sa, base * 4, t.jump_rounds, isb);
+  COL_T(2)
   // geom frames: lane = geom (chunks of 32), body pose fetched from the body's lane
   const tp_lds_d G = (tp_lds_d)gfr + (tid / TP_LPE) * (cm.ngeom * TPG_SLOT);
   for (int g0 = 0; g0 < cm.ngeom; g0 += TP_LPE) {
@@ -818,6 +826,7 @@ __device__ __forceinline__ void tp_collide_prep(const DevModel& m, const TpModel
     }
   }
   tp_wave_sync();
+  COL_T(3)
   // broadphase over the candidate pairs, in pair order
   int count = 0;
   for (int p0 = 0; p0 < cm.npair; p0 += TP_LPE) {
@@ -866,6 +875,7 @@ __device__ __forceinline__ void tp_collide_prep(const DevModel& m, const TpModel
     if (count > cm.maxcand) AT(d.warning, 0) |= 8;
     AT(cd.ncand, 0) = count > cm.maxcand ? cm.maxcand : count;
   }
+  COL_T(4)
   // work list for the narrowphase: the environment reserves `count` consecutive items of its sub-list
   if (count > cm.maxcand) count = cm.maxcand;
   const int sub = blockIdx.x & (BS_NSUB - 1);
