@@ -314,6 +314,8 @@ extern "C" int bs_model_create(const bs_model_desc* desc, bs_model** out) {
     if (desc->npair > 0 && !(desc->disableflags & BS_DSBL_CONTACT) && desc->geom_condim[g] != 1 && desc->geom_condim[g] != 3)
       return fail(BS_ERR_UNSUPPORTED, "geom %d: condim %d (only 1 and 3 are implemented)", g, desc->geom_condim[g]);
   }
+  if (desc->npair > 0 && desc->ngeom > 0xFFF)
+    return fail(BS_ERR_UNSUPPORTED, "bs_model_create: %d geoms (the per-pair records hold 12-bit geom ids)", desc->ngeom);
   for (int me = 0; me < desc->nmesh; me++)
     for (int v = desc->mesh_vertadr[me]; v < desc->mesh_vertadr[me] + desc->mesh_vertnum[me]; v++) {
       if (desc->hull_adj_start[v] < 0 || desc->hull_adj_start[v + 1] < desc->hull_adj_start[v] ||
@@ -672,6 +674,25 @@ static int model_image(bs_model* m, int device, const DeviceImage** out) {
     for (int k = 0; k < 3; k++) { obb[6 * g + k] = 0.5 * (lo[k] + hi[k]); obb[6 * g + 3 + k] = 0.5 * (hi[k] - lo[k]); }
   }
   PUT_CD(geom_obb, obb.data(), obb.size());
+  // broadphase record of a pair: both geoms, which bounding test applies and its threshold (k_tp_col's first pass)
+  std::vector<int32_t> pbp((size_t)(s.npair > 0 ? s.npair : 1) * 4, 0);
+  for (int p = 0; p < s.npair; p++) {
+    const int g1 = s.pair_geom1[p], g2 = s.pair_geom2[p];
+    const double margin = fmax(s.geom_margin[g1], s.geom_margin[g2]);
+    const double r1 = s.geom_rbound[g1], r2 = s.geom_rbound[g2];
+    int kind = 0, has_box = 0;
+    double thresh = 0.0;
+    if (r1 > 0 && r2 > 0) {
+      kind = 1; thresh = margin + r1 + r2;
+      has_box = obb[6 * g1 + 3] >= 0 && obb[6 * g2 + 3] >= 0;
+    } else if (s.geom_type[g1] == BS_GEOM_PLANE && r2 > 0) {
+      kind = 2; thresh = margin + r2;
+    }
+    int32_t* r = &pbp[(size_t)p * 4];
+    r[0] = g1 | (g2 << 12) | (kind << 24) | (has_box << 26);
+    memcpy(r + 2, &thresh, sizeof thresh);
+  }
+  PUT_CI(pair_bp, pbp.data(), pbp.size());
   std::vector<double> gsize((size_t)(ng > 0 ? ng : 1) * 3, 0.0);
   if (s.geom_size) memcpy(gsize.data(), s.geom_size, (size_t)ng * 3 * sizeof(double));
   PUT_CD(geom_size, gsize.data(), gsize.size());
@@ -822,7 +843,7 @@ static void launch_tpc_pass(bs_sim* s, const DevData& dd, hipStream_t st, int mo
   if (const char* e = getenv("BS_COLCUT")) bs_set_colcut(atoi(e));
 #endif
   const dim3 g((unsigned)((dd.n_envs - dd.env0 + 1) / 2));
-  const size_t lds_col = (size_t)2 * s->cm.ngeom * TPG_SLOT * sizeof(double);
+  const size_t lds_col = (size_t)2 * s->cm.ngeom * TPG_SLOT * sizeof(double) + (size_t)2 * s->cm.npair * sizeof(int);  // frames, pair lists
   bs_launch_tp_col(g, lds_col, st, s->dm, s->tp, dd, s->cm, s->cd);
   if (s->narrow_ws || s->narrow_blocks) {
     launch_narrow(s, dd, st);

@@ -827,39 +827,59 @@ __device__ __forceinline__ void tp_collide_prep(const DevModel& m, const TpModel
   }
   tp_wave_sync();
   COL_T(3)
-  // broadphase over the candidate pairs, in pair order
-  int count = 0;
+  // broadphase over the candidate pairs, in pair order.  Pass 1: bounding spheres (plane: signed distance) for
+  // every pair, survivors compacted IN ORDER into an LDS list; pass 2: the oriented-box filter over that list only
+  // (a wavefront runs the fifteen-axis test when any of its lanes needs it: over all pairs that was every
+  // trip, over the survivors it is one trip or two), then the ordered reservation of candidate slots.
+  const tp_lds_i L = (tp_lds_i)((tp_lds_d)gfr + 2 * cm.ngeom * TPG_SLOT) + (tid / TP_LPE) * cm.npair;
+  const unsigned lower = (1u << l) - 1u;
+  int nlist = 0;
   for (int p0 = 0; p0 < cm.npair; p0 += TP_LPE) {
     const int p = p0 + l;
-    bool keep = false;
+    bool keep = false, obb = false;
     if (p < cm.npair) {
-      const int g1 = cm.pair_geom1[p], g2 = cm.pair_geom2[p];
-      const int t1 = cm.geom_type[g1];
-      {
+      const int4 rec = *(const int4*)(cm.pair_bp + 4 * p);
+      const int g1 = rec.x & 0xfff, g2 = (rec.x >> 12) & 0xfff, kind = (rec.x >> 24) & 3;
+      const double thresh = __hiloint2double(rec.w, rec.z);
+      const tp_lds_d s1 = G + g1 * TPG_SLOT, s2 = G + g2 * TPG_SLOT;
+      const V3 x1 = {s1[0], s1[1], s1[2]}, x2 = {s2[0], s2[1], s2[2]};
+      keep = true;
+      if (kind == 1) {
+        const V3 df = sub(x1, x2);
+        keep = !(sqrt(dot(df, df)) > thresh);
+        obb = keep && (rec.x >> 26 & 1);
+      } else if (kind == 2) {
+        const V3 n = {s1[3 + 2], s1[3 + 5], s1[3 + 8]};
+        keep = !(dot(sub(x2, x1), n) > thresh);
+      }
+    }
+    const unsigned mk = (unsigned)(__ballot(keep) >> base);
+    if (keep) L[nlist + __popc(mk & lower)] = p | (obb ? 1 << 30 : 0);
+    nlist += __popc(mk);
+  }
+  tp_wave_sync();
+  int count = 0;
+  for (int i0 = 0; i0 < nlist; i0 += TP_LPE) {
+    const int i = i0 + l;
+    bool keep = i < nlist;
+    int p = 0;
+    if (keep) {
+      const int v = L[i];
+      p = v & ~(1 << 30);
+      if (v >> 30) {
+        const int g1 = cm.pair_geom1[p], g2 = cm.pair_geom2[p];
         const double margin = fmax(cm.geom_margin[g1], cm.geom_margin[g2]);
-        const double r1 = cm.geom_rbound[g1], r2 = cm.geom_rbound[g2];
         const tp_lds_d s1 = G + g1 * TPG_SLOT, s2 = G + g2 * TPG_SLOT;
         const V3 x1 = {s1[0], s1[1], s1[2]}, x2 = {s2[0], s2[1], s2[2]};
-        keep = true;
-        if (r1 > 0 && r2 > 0) {
-          const V3 df = sub(x1, x2);
-          keep = !(sqrt(dot(df, df)) > margin + r1 + r2);
-          if (keep && cm.geom_obb[6 * g1 + 3] >= 0 && cm.geom_obb[6 * g2 + 3] >= 0) {
-            double A[9], B[9];
+        double A[9], B[9];
 #pragma unroll
-            for (int k = 0; k < 9; k++) { A[k] = s1[3 + k]; B[k] = s2[3 + k]; }
-            keep = !obb_separated_m(cm.geom_obb + 6 * g1, cm.geom_obb + 6 * g2, A, B, x1, x2, margin);
-          }
-        } else if (t1 == BS_GEOM_PLANE && r2 > 0) {
-          const V3 n = {s1[3 + 2], s1[3 + 5], s1[3 + 8]};
-          keep = !(dot(sub(x2, x1), n) > margin + r2);
-        }
+        for (int k = 0; k < 9; k++) { A[k] = s1[3 + k]; B[k] = s2[3 + k]; }
+        keep = !obb_separated_m(cm.geom_obb + 6 * g1, cm.geom_obb + 6 * g2, A, B, x1, x2, margin);
       }
     }
     // a pair reserves pair_nsub consecutive slots (1, 2 or 8; 0 for geom types no routine handles):
     // ordered compaction with a prefix sum of the counts from three ballots
     const int cnt = keep ? cm.pair_nsub[p] : 0;
-    const unsigned lower = (1u << l) - 1u;
     const unsigned m1 = (unsigned)(__ballot(cnt & 1) >> base), m2 = (unsigned)(__ballot(cnt & 2) >> base),
                    m8 = (unsigned)(__ballot(cnt & 8) >> base);
     const int at = count + __popc(m1 & lower) + 2 * __popc(m2 & lower) + 8 * __popc(m8 & lower);
