@@ -824,7 +824,10 @@ static int ensure_serial_contact(bs_sim* s) {
   return BS_OK;
 }
 static inline dim3 grid_for(const bs_sim* s) { return dim3((unsigned)((s->n_envs + BS_BLOCK - 1) / BS_BLOCK)); }
-static inline dim3 grid_tp(const bs_sim* s) { return dim3((unsigned)((s->n_envs + 1) / 2)); }
+// tree-parallel kernels: one wavefront per pair of environments, the grid rounded up to whole rounds of the 8 XCDs
+// (physics_tp.h::tp_block deals each XCD a contiguous run of pairs)
+static inline dim3 grid_tp_n(long n_envs) { return dim3((unsigned)(((n_envs + 1) / 2 + 7) / 8 * 8)); }
+static inline dim3 grid_tp(const bs_sim* s) { return grid_tp_n(s->n_envs); }
 // narrowphase: flattened work items by default; BS_NARROW=ws selects the work-stealing variant
 // (measured slower on MI355X at 65536 envs: 2.6 ms vs 1.9 ms)
 static void launch_narrow(bs_sim* s, const DevData& dd, hipStream_t st) {
@@ -842,7 +845,7 @@ static void launch_tpc_pass(bs_sim* s, const DevData& dd, hipStream_t st, int mo
   extern void bs_set_colcut(int);
   if (const char* e = getenv("BS_COLCUT")) bs_set_colcut(atoi(e));
 #endif
-  const dim3 g((unsigned)((dd.n_envs - dd.env0 + 1) / 2));
+  const dim3 g = grid_tp_n(dd.n_envs - dd.env0);
   const size_t lds_col = (size_t)2 * s->cm.ngeom * TPG_SLOT * sizeof(double) + (size_t)2 * s->cm.npair * sizeof(int);  // frames, pair lists
   bs_launch_tp_col(g, lds_col, st, s->dm, s->tp, dd, s->cm, s->cd);
   if (s->narrow_ws || s->narrow_blocks) {

@@ -181,6 +181,12 @@ __device__ __forceinline__ constexpr int pair_idx(int a, int b) {  // 1 <= a <= 
 }
 
 typedef const int __attribute__((address_space(3))) * tp_lds_ptr;  // lane table in LDS
+// Which pair of environments a workgroup steps.  Blocks are dealt round-robin over the 8 XCDs (b and b + 8 share
+// one), each XCD with its own L2, and the state arrays are [field][E]: a 128-byte line holds one field of 16
+// environments = 8 consecutive pairs.  With pair = blockIdx the eight blocks that share a line sit on eight XCDs
+// and every L2 fetches (and partially writes) every line; dealing each XCD a contiguous run of pairs keeps a line
+// in one L2.  The grid is a multiple of 8 blocks (batchsim.hip::grid_tp_n); pairs past the batch are idle.
+__device__ __forceinline__ int tp_block() { return (int)((blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3)); }
 typedef double __attribute__((address_space(3))) * tp_lds_d;
 typedef int __attribute__((address_space(3))) * tp_lds_i;
 
@@ -757,7 +763,7 @@ __device__ __forceinline__ void tp_collide_prep(const DevModel& m, const TpModel
   COL_T(0)
   const int tid = threadIdx.x;
   const int l = tid & (TP_LPE - 1), base = tid & ~(TP_LPE - 1);
-  long env = d.env0 + (long)blockIdx.x * (64 / TP_LPE) + (tid / TP_LPE);
+  long env = d.env0 + (long)tp_block() * (64 / TP_LPE) + (tid / TP_LPE);
   const bool env_ok = env < d.n_envs;
   if (!env_ok) env = d.n_envs - 1;
   const long E = d.E, e = env;
@@ -967,7 +973,7 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
   for (int f = 0; f < 2 * TP_MAXC; f++) tbl[f * 64 + tid] = lane_ref(TPI_BCHILD + f);
   tbl[TPL_ANCMASK * 64 + tid] = t.lane[TPI_ANCMASK * TP_LPE + l];
   __syncthreads();
-  long env = d.env0 + (long)blockIdx.x * (64 / TP_LPE) + (tid / TP_LPE);
+  long env = d.env0 + (long)tp_block() * (64 / TP_LPE) + (tid / TP_LPE);
   const bool env_ok = env < d.n_envs;
   if (!env_ok) env = d.n_envs - 1;
   const long E = d.E, e = env;
