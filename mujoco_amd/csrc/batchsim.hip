@@ -884,15 +884,7 @@ static void launch_contact_pass(bs_sim* s, int check, int integrate, int dump = 
 static void launch_step(bs_sim* s, int n_steps) {
   if (s->contacts) {
     // outputs of the forward pass (poses, generalized forces) are only observable after the last step
-    if (s->dm.integrator == 1) {  // RK4: four forward passes (collision included), state moved in between
-      for (int k = 0; k < n_steps; k++)
-        for (int i = 1; i <= 4; i++) {
-          if (i == 1) bs_launch_check_state(grid_for(s), s->stream, s->dm, s->dd);
-          launch_contact_pass(s, 0, 0, i == 4 && k == n_steps - 1, 1);
-          bs_launch_rk4_advance(grid_for(s), s->stream, s->dm, s->dd, i);
-        }
-      return;
-    }
+    const bool rk = s->dm.integrator == 1;  // RK4: four forward passes (collision included), state moved in between
     if (s->use_tpc && s->split > 1) {
       // range 0 on the sim's stream, the others on auxiliary streams, joined at the end
       const int np = s->split;
@@ -907,12 +899,31 @@ static void launch_step(bs_sim* s, int n_steps) {
       (void)hipEventRecord(s->fork_ev, s->stream);
       for (int q = 1; q < np; q++) (void)hipStreamWaitEvent(s->aux_stream[q - 1], s->fork_ev, 0);
       for (int k = 0; k < n_steps; k++)
-        for (int q = 0; q < np; q++)
-          launch_tpc_pass(s, part[q], q == 0 ? s->stream : s->aux_stream[q - 1], 0, k == n_steps - 1);
+        for (int i = 1; i <= (rk ? 4 : 1); i++)
+          for (int q = 0; q < np; q++) {
+            hipStream_t st = q == 0 ? s->stream : s->aux_stream[q - 1];
+            if (!rk) {
+              launch_tpc_pass(s, part[q], st, 0, k == n_steps - 1);
+              continue;
+            }
+            const dim3 gq((unsigned)((part[q].n_envs - part[q].env0 + BS_BLOCK - 1) / BS_BLOCK));
+            if (i == 1) bs_launch_check_state(gq, st, s->dm, part[q]);
+            launch_tpc_pass(s, part[q], st, 1, i == 4 && k == n_steps - 1);
+            bs_launch_rk4_advance(gq, st, s->dm, part[q], i);
+          }
       for (int q = 1; q < np; q++) {
         (void)hipEventRecord(s->join_ev[q - 1], s->aux_stream[q - 1]);
         (void)hipStreamWaitEvent(s->stream, s->join_ev[q - 1], 0);
       }
+      return;
+    }
+    if (rk) {
+      for (int k = 0; k < n_steps; k++)
+        for (int i = 1; i <= 4; i++) {
+          if (i == 1) bs_launch_check_state(grid_for(s), s->stream, s->dm, s->dd);
+          launch_contact_pass(s, 0, 0, i == 4 && k == n_steps - 1, 1);
+          bs_launch_rk4_advance(grid_for(s), s->stream, s->dm, s->dd, i);
+        }
       return;
     }
     for (int k = 0; k < n_steps; k++) launch_contact_pass(s, 1, 1, k == n_steps - 1);
@@ -1173,7 +1184,7 @@ extern "C" int bs_sim_create(const bs_model* const* models, int n_models, const 
     const char* sp = getenv("BS_SPLIT");
     int np = sp ? atoi(sp) : (n_envs >= 8192 ? 3 : 1);  // measured: 3 ranges win from 8192 envs (14.6 vs 12.7 M env-steps/s; 27.5 vs 26.9 M at 65 536), 4 lose
     np = np < 1 ? 1 : (np > 4 ? 4 : np);
-    if (!s->use_tpc || s->dm.integrator == 1) np = 1;
+    if (!s->use_tpc) np = 1;
     while (np > 1 && (n_envs < 128L * np || split_chunk(n_envs, np) * (np - 1) >= n_envs)) np--;
     s->split = np;
     if (np >= 3 && !getenv("BS_NL_GRID")) s->nl_grid = 1024;  // three narrowphase launches share the machine

@@ -47,14 +47,14 @@ __global__ __launch_bounds__(BS_BLOCK) void k_reset(DevModel m, DevData d, const
 }
 // A14 mj_checkPos / mj_checkVel on their own (the RK4 step with contacts starts with it)
 __global__ __launch_bounds__(BS_BLOCK) void k_check_state(DevModel m, DevData d) {
-  const long e = (long)blockIdx.x * BS_BLOCK + threadIdx.x;
+  const long e = d.env0 + (long)blockIdx.x * BS_BLOCK + threadIdx.x;  // a range [env0, n_envs) of the batch
   if (e >= d.n_envs) return;
   env_check(m, d, e, d.qpos, m.njnt, 0);
   env_check(m, d, e, d.qvel, m.nv, 1);
 }
 // RK4 across launches (contacts): see rk4_advance
 __global__ __launch_bounds__(BS_BLOCK) void k_rk4_advance(DevModel m, DevData d, int i) {
-  const long e = (long)blockIdx.x * BS_BLOCK + threadIdx.x;
+  const long e = d.env0 + (long)blockIdx.x * BS_BLOCK + threadIdx.x;
   if (e >= d.n_envs) return;
   rk4_advance(m, d, e, i);
 }

@@ -155,6 +155,26 @@ def test_small_batch_default_path_9000_envs(hand_model):
     _check_contact_samples(sim, m, q, c, ids, 10)
 
 
+def test_rk4_contacts_default_path_9001_envs(hand_model):
+    """RK4 with contacts on the default path at a size that engages the three-range split: every range
+    runs its own state check, four collision + dynamics passes and RK4 advances on its stream."""
+    import os
+    from mujoco_amd import workload
+    from mujoco_amd.model import INT_RK4
+    assert "BS_SPLIT" not in os.environ
+    m = workload.with_ground_plane(hand_model, z=-0.05).copy()
+    m.opt_integrator = INT_RK4
+    E = 9001
+    sim, q, v, c = _contact_run(m, E, 1241, 4)
+    chunk = (E // 3 + 63) // 64 * 64
+    ids = _samples(E, extra=(chunk - 1, chunk, 2 * chunk - 1, 2 * chunk, E - 1))
+    sim.step(4); sim.sync()
+    assert np.isfinite(sim.data.qpos.cpu().numpy()).all()
+    assert int((sim.data.warning != 0).sum()) == 0
+    assert np.abs(sim.data.time.cpu().numpy() - 4 * m.opt_timestep).max() < 1e-12
+    assert _check_contact_samples(sim, m, q, c, ids, 4) > 32
+
+
 def test_config4_per_gpu_share_131072_envs_with_obs_gather(hand_model):
     """configs[4], one GPU's share: 131 072 envs with contacts + the per-control-period all-gather of
     obs / reward over RCCL (one rank: the collective, its overlap with the next steps and the pack

@@ -380,12 +380,17 @@ def test_rk4_with_contacts(hand_model, kernel, solver, monkeypatch):
         assert sorted((g1, g2) for g1, g2, _ in sim.data.contacts(e)) == sorted((cc["geom1"], cc["geom2"]) for cc in s.contacts())
 
 
-def test_two_stream_split_is_bitwise_neutral(hand_model, monkeypatch):
+@pytest.mark.parametrize("integrator", ["euler", "rk4"])
+def test_two_stream_split_is_bitwise_neutral(hand_model, integrator, monkeypatch):
     """BS_SPLIT=n runs ranges of a contact batch on separate streams (overlap of the narrowphase with
-    the dynamics kernel); it must not change a single bit of the result."""
+    the dynamics kernel); it must not change a single bit of the result.  RK4: each range runs its own
+    check / four passes / advances sequence (k_check_state and k_rk4_advance take the range)."""
     import torch
     from mujoco_amd import BatchSim, workload
     m = _contact_model(hand_model)
+    if integrator == "rk4":
+        from mujoco_amd.model import INT_RK4
+        m.opt_integrator = INT_RK4
     E = 389
     q, v = workload.config2_state(m, E, seed=123)
     c = workload.config2_ctrl(m, E, seed=123)
