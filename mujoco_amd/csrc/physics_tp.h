@@ -40,7 +40,9 @@ enum {
 
 // fields kept in LDS (indexed inside loops or by another lane's id); the rest is read once
 // from the table in global memory into registers
-enum { TPL_BCHILD = 0, TPL_DCHILD = TP_MAXC, TPL_ANCMASK = 2 * TP_MAXC, TPL_TOTAL = 2 * TP_MAXC + 1 };
+// LDS table rows (64 ints each): children 1.. of a body / dof as LANE BYTES, four per int (child 0 is held in a
+// register; "none" is stored as the environment's zero lane, so a reader needs no test), then the ancestor masks
+enum { TPL_CROWS = (TP_MAXC - 1 + 3) / 4, TPL_BCHILD = 0, TPL_DCHILD = TPL_CROWS, TPL_ANCMASK = 2 * TPL_CROWS, TPL_TOTAL = 2 * TPL_CROWS + 1 };
 
 // per-lane constants of the lane's constraint rows, [field][32]: everything in mj_makeImpedance /
 // mj_referenceConstraint that does not depend on the state (K, B of the rows' solref; the whole
@@ -227,6 +229,11 @@ struct TpCtx {
                          // so the sweeps' usual case needs no table read in front of the permutes
   tp_lds_ptr tbl;        // LDS table
 };
+// ds_bpermute address of child ch >= 1 of this lane (row0 = TPL_BCHILD or TPL_DCHILD)
+__device__ __forceinline__ int tp_child(tp_lds_ptr tbl, int row0, int ch) {
+  const int w = tbl[(row0 + ((ch - 1) >> 2)) * 64 + threadIdx.x];
+  return ((w >> (((ch - 1) & 3) * 8)) & 0xff) << 2;
+}
 
 // sparse L^T D L of the distributed rows (mj_factorM layout): R[0] diagonal, R[a] the entry with
 // the a-th ancestor dof.  Level by level from the leaves: a finished dof sends the outer-product
@@ -260,8 +267,8 @@ __device__ TP_HELPER_ATTR TpFac tp_factor(TpCtx c, TpRow Rin) {
     if (D == 1) break;
     const bool par = c.dd == D - 1;
     for (int ch = 0; ch < c.nchild[D]; ch++) {
-      const int src = ch == 0 ? c.dchild0 : c.tbl[(TPL_DCHILD + ch) * 64 + threadIdx.x];
-      const int sa = par && src >= 0 ? src : c.zero_sa;
+      const int src = ch == 0 ? c.dchild0 : tp_child(c.tbl, TPL_DCHILD, ch);
+      const int sa = par ? src : c.zero_sa;
 #pragma unroll
       for (int a = 1; a < TP_MAXD; a++) {
         if (a >= D) continue;
@@ -315,8 +322,8 @@ __device__ TP_HELPER_ATTR double tp_factor_solve(TpCtx c, TpRow Rin, double x) {
     if (D == 1) break;
     const bool par = c.dd == D - 1;
     for (int ch = 0; ch < c.nchild[D]; ch++) {
-      const int src = ch == 0 ? c.dchild0 : c.tbl[(TPL_DCHILD + ch) * 64 + threadIdx.x];
-      const int sa = par && src >= 0 ? src : c.zero_sa;
+      const int src = ch == 0 ? c.dchild0 : tp_child(c.tbl, TPL_DCHILD, ch);
+      const int sa = par ? src : c.zero_sa;
 #pragma unroll
       for (int a = 1; a < TP_MAXD; a++) {
         if (a >= D) continue;
@@ -383,8 +390,8 @@ __device__ TP_HELPER_ATTR void tp_factor2(TpCtx c, TpRow R0in, TpRow R1in, TpFac
     if (D == 1) break;
     const bool par = c.dd == D - 1;
     for (int ch = 0; ch < c.nchild[D]; ch++) {
-      const int src = ch == 0 ? c.dchild0 : c.tbl[(TPL_DCHILD + ch) * 64 + threadIdx.x];
-      const int sa = par && src >= 0 ? src : c.zero_sa;
+      const int src = ch == 0 ? c.dchild0 : tp_child(c.tbl, TPL_DCHILD, ch);
+      const int sa = par ? src : c.zero_sa;
 #pragma unroll
       for (int a = 1; a < TP_MAXD; a++) {
         if (a >= D) continue;
@@ -421,8 +428,8 @@ __device__ TP_HELPER_ATTR double tp_solve(TpCtx c, TpRow Rin, double dinv, doubl
     for (int a = 1; a < TP_MAXD; a++)
       if (a < D) T[a] = is ? R[a] * x + W[a] : 0.0;
     for (int ch = 0; ch < c.nchild[D]; ch++) {
-      const int src = ch == 0 ? c.dchild0 : c.tbl[(TPL_DCHILD + ch) * 64 + threadIdx.x];
-      const int sa = par && src >= 0 ? src : c.zero_sa;
+      const int src = ch == 0 ? c.dchild0 : tp_child(c.tbl, TPL_DCHILD, ch);
+      const int sa = par ? src : c.zero_sa;
 #pragma unroll
       for (int a = 1; a < TP_MAXD; a++) {
         if (a >= D) continue;
@@ -471,8 +478,8 @@ __device__ TP_HELPER_ATTR double tp_solve_mulm(TpCtx c, TpRow Rin, double dinv, 
     for (int a = 1; a < TP_MAXD; a++)
       if (a < D) { T[a] = is ? R[a] * x + W[a] : 0.0; U[a] = is ? Mr[a] * v + V[a] : 0.0; }
     for (int ch = 0; ch < c.nchild[D]; ch++) {
-      const int src = ch == 0 ? c.dchild0 : c.tbl[(TPL_DCHILD + ch) * 64 + threadIdx.x];
-      const int sa = par && src >= 0 ? src : c.zero_sa;
+      const int src = ch == 0 ? c.dchild0 : tp_child(c.tbl, TPL_DCHILD, ch);
+      const int sa = par ? src : c.zero_sa;
 #pragma unroll
       for (int a = 1; a < TP_MAXD; a++) {
         if (a >= D) continue;
@@ -518,8 +525,8 @@ __device__ TP_HELPER_ATTR void tp_solve_n(TpCtx c, TpRow Rin, double dinv, doubl
       for (int a = 1; a < TP_MAXD; a++)
         if (a < D) T[n][a] = is ? R[a] * x[n] + W[n][a] : 0.0;
     for (int ch = 0; ch < c.nchild[D]; ch++) {
-      const int src = ch == 0 ? c.dchild0 : c.tbl[(TPL_DCHILD + ch) * 64 + threadIdx.x];
-      const int sa = par && src >= 0 ? src : c.zero_sa;
+      const int src = ch == 0 ? c.dchild0 : tp_child(c.tbl, TPL_DCHILD, ch);
+      const int sa = par ? src : c.zero_sa;
 #pragma unroll
       for (int a = 1; a < TP_MAXD; a++) {
         if (a >= D) continue;
@@ -572,8 +579,8 @@ __device__ TP_HELPER_ATTR double tp_mul_m(TpCtx c, TpRow Min, double v) {
     for (int a = 1; a < TP_MAXD; a++)
       if (a < D) T[a] = is ? Mr[a] * v + W[a] : 0.0;
     for (int ch = 0; ch < c.nchild[D]; ch++) {
-      const int src = ch == 0 ? c.dchild0 : c.tbl[(TPL_DCHILD + ch) * 64 + threadIdx.x];
-      const int sa = par && src >= 0 ? src : c.zero_sa;
+      const int src = ch == 0 ? c.dchild0 : tp_child(c.tbl, TPL_DCHILD, ch);
+      const int sa = par ? src : c.zero_sa;
 #pragma unroll
       for (int a = 1; a < TP_MAXD; a++) {
         if (a >= D) continue;
@@ -970,7 +977,19 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
   // lane table: lane references become ds_bpermute byte addresses; child lists and ancestor
   // masks go to LDS, everything else straight into registers
   auto lane_ref = [&](int f) { const int v = t.lane[f * TP_LPE + l]; return v >= 0 ? (base + v) * 4 : v; };
-  for (int f = 0; f < 2 * TP_MAXC; f++) tbl[f * 64 + tid] = lane_ref(TPI_BCHILD + f);
+  {
+    const int zl = base + TP_LPE - 1;  // the environment's zero lane stands for "no child"
+    for (int r = 0; r < 2 * TPL_CROWS; r++) {
+      const int first = (r < TPL_CROWS ? TPI_BCHILD : TPI_DCHILD) + 1 + 4 * (r % TPL_CROWS);
+      int w = 0;
+      for (int k = 0; k < 4; k++) {
+        const int ch = 1 + 4 * (r % TPL_CROWS) + k;
+        const int v = ch < TP_MAXC ? t.lane[(first + k) * TP_LPE + l] : -1;
+        w |= (v >= 0 ? base + v : zl) << (8 * k);
+      }
+      tbl[r * 64 + tid] = w;
+    }
+  }
   tbl[TPL_ANCMASK * 64 + tid] = t.lane[TPI_ANCMASK * TP_LPE + l];
   __syncthreads();
   long env = d.env0 + (long)tp_block() * (64 / TP_LPE) + (tid / TP_LPE);
@@ -991,7 +1010,9 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
   TpCtx c;
   c.self_sa = self_sa; c.zero_sa = (base + TP_LPE - 1) * 4; c.dd = has_dof ? t.lane[TPI_DD * TP_LPE + l] : 0; c.maxdd = t.maxdd; c.tbl = (tp_lds_ptr)tbl;
   c.dchild0 = lane_ref(TPI_DCHILD);
-  const int bchild0 = lane_ref(TPI_BCHILD);
+  if (c.dchild0 < 0) c.dchild0 = (base + TP_LPE - 1) * 4;
+  int bchild0 = lane_ref(TPI_BCHILD);
+  if (bchild0 < 0) bchild0 = (base + TP_LPE - 1) * 4;
 #pragma unroll
   for (int a = 0; a < TP_MAXD; a++) {
     const int v = lane_ref(TPI_ANC + a);
@@ -1170,8 +1191,8 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
         for (int lvl = t.maxdepth; lvl >= (FULL ? 2 : t.fold_minlvl); lvl--) {
           const bool par = isb && depth == lvl - 1;
           for (int ch = 0; ch < t.lvl_bchild[lvl]; ch++) {
-            const int src = ch == 0 ? bchild0 : tbl[(TPL_BCHILD + ch) * 64 + tid];
-            const int sa = par && src >= 0 ? src : c.zero_sa;
+            const int src = ch == 0 ? bchild0 : tp_child(c.tbl, TPL_BCHILD, ch);
+            const int sa = par ? src : c.zero_sa;
 #pragma unroll
             for (int k = 0; k < 10; k++) crb[k] += bperm(crb[k], sa);
 #pragma unroll
