@@ -2185,6 +2185,7 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
       }
     }
   }
+  TPC_C(26)
 #ifdef TPC_PROFILE
   TPC_T(11)
   if constexpr (CON) {
