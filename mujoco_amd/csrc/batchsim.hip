@@ -708,8 +708,19 @@ static int model_image(bs_model* m, int device, const DeviceImage** out) {
 #undef PUT_CI
 #undef PUT_CD
   TpModel tp = m->tp;
-  tp.lane = nullptr; tp.lane_d = nullptr; tp.lane_k = nullptr; tp.pgs_order = nullptr;
+  tp.lane = nullptr; tp.lane_d = nullptr; tp.lane_k = nullptr; tp.pgs_order = nullptr; tp.tri_pk = nullptr;
+  // row of the packed lower-triangle entry q = l + 32 t (k_tpc's dense Cholesky deals the entries round-robin)
+  std::vector<uint64_t> tri_pk(2 * TP_LPE, 0);
+  for (int l = 0; l < TP_LPE; l++)
+    for (int tt = 0; tt < TPC_NTRI; tt++) {
+      const int q = l + tt * TP_LPE;
+      int i = 0;
+      while ((i + 1) * (i + 2) / 2 <= q) i++;
+      if (tt < 12) tri_pk[l] |= (uint64_t)(i & 31) << (5 * tt);
+      else tri_pk[TP_LPE + l] |= (uint64_t)(i & 31) << (5 * (tt - 12));
+    }
   if (m->tp_ok) {
+    fix.push_back({pk.add(tri_pk.data(), tri_pk.size() * sizeof(uint64_t)), (void**)&tp.tri_pk});
     fix.push_back({pk.add(m->tp_pgs.data(), m->tp_pgs.size() * sizeof(int32_t)), (void**)&tp.pgs_order});
     fix.push_back({pk.add(m->tp_table.data(), m->tp_table.size() * sizeof(int32_t)), (void**)&tp.lane});
     fix.push_back({pk.add(m->tp_dtable.data(), m->tp_dtable.size() * sizeof(double)), (void**)&tp.lane_d});

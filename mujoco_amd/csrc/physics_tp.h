@@ -73,6 +73,7 @@ struct TpModel {
   const int* lane;  // [TPI_TOTAL][32]
   const double* lane_d;  // [TPD_TOTAL][32]
   const double* lane_k;  // [32][TPK_N]
+  const unsigned long long* tri_pk;  // [2][32]: row index (5 bits each) of the packed lower-triangle entries q = l + 32 t, t = 0..11 | 12..
   int maxdepth, maxdd, nroots;
   int jump_rounds;  // ceil(log2(maxdepth)): pointer-jumping rounds that reach the world from every body
   int fold_minlvl;  // leaves-to-root folds (crb, rne forces) stop here: no body above this depth carries a dof
@@ -1606,16 +1607,8 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
           // The forward substitution L^T y = g rides along: g is one more row of the trailing update, every
           // lane keeps its own entry in a register and publishes it in Gs for the panel that needs it.
           // row index of packed entry q = l + 32 t, 5 bits each (a table of ints would be spilled)
-          unsigned long long pk0 = 0, pk1 = 0;  // chunks 0..11 and 12..
-#pragma unroll
-          for (int tt = 0; tt < TPC_NTRI; tt++) {
-            const int q = l + tt * TP_LPE;
-            int i = (int)((__fsqrt_rn(8.0f * (float)q + 1.0f) - 1.0f) * 0.5f);
-            if ((i + 1) * (i + 2) / 2 <= q) i++;
-            if (i * (i + 1) / 2 > q) i--;
-            if (tt < 12) pk0 |= (unsigned long long)(i & 31) << (5 * tt);
-            else pk1 |= (unsigned long long)(i & 31) << (5 * (tt - 12));
-          }
+          // (host table: computed here it cost ~450 VALU instructions per launch, float sqrt + fix-ups per chunk)
+          const unsigned long long pk0 = t.tri_pk[l], pk1 = t.tri_pk[TP_LPE + l];  // chunks 0..11 and 12..
           const tp_lds_d Gs = Us;  // the U staging rows are free again
           double greg = g, y = 0;
           Gs[l] = greg;
