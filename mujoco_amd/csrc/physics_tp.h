@@ -89,6 +89,20 @@ struct TpModel {
 // sincos out of line: inlined into the step loop, its polynomial coefficients are hoisted out of the loop as
 // register pairs, spilled, and reloaded from scratch one dependent round trip at a time inside every call
 __device__ __attribute__((noinline)) void tp_sincos(double x, double* sn, double* cs) { sincos(x, sn, cs); }
+// 1 / sqrt(x) for x in the normal range: v_rsq_f64 refined by three Goldschmidt rounds (the last one for h only),
+// 12 VALU instructions against ~40 for an IEEE sqrt followed by an IEEE division; within an ulp or two, not
+// correctly rounded.  For the pivots of k_tpc's dense Cholesky (24 of them per Newton iteration).
+__device__ __forceinline__ double tp_rsqrt(double x) {
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = 0.5 * y;
+  double r = fma(-h, g, 0.5);
+  g = fma(g, r, g); h = fma(h, r, h);
+  r = fma(-h, g, 0.5);
+  g = fma(g, r, g); h = fma(h, r, h);
+  r = fma(-h, g, 0.5);
+  h = fma(h, r, h);
+  return h + h;
+}
 // ---- cross-lane primitives.  `sa` arguments are ds_bpermute byte addresses (lane * 4).
 __device__ __forceinline__ double bperm(double v, int sa) {
   const int lo = __builtin_amdgcn_ds_bpermute(sa, __double2loint(v));
@@ -1618,7 +1632,7 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
             const tp_lds_d H1 = Hs + t1;
             double d1 = H1[j1];
             if (d1 < BS_MINVAL) d1 = BS_MINVAL;
-            const double inv1 = 1.0 / sqrt(d1);
+            const double inv1 = tp_rsqrt(d1);
             const double y1 = Gs[j1] * inv1;
             if (j0 < 0) {  // n odd: the last column stands alone and has nothing to update
               if (l == 0) { H1[0] = inv1; y = y1; }
@@ -1630,7 +1644,7 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
             const double l10 = H1[j0] * inv1;
             double d0 = H0[j0] - l10 * l10;
             if (d0 < BS_MINVAL) d0 = BS_MINVAL;
-            const double inv0 = 1.0 / sqrt(d0);
+            const double inv0 = tp_rsqrt(d0);
             const double y0 = (Gs[j0] - l10 * y1) * inv0;
             if (l < j0) {
               const double a = H1[l] * inv1, b = (H0[l] - l10 * a) * inv0;
