@@ -103,6 +103,16 @@ __device__ __forceinline__ double tp_rsqrt(double x) {
   h = fma(h, r, h);
   return h + h;
 }
+// 1 / x for finite nonzero x in the normal range: v_rcp_f64 and two Newton steps, 5 VALU instructions against ~25
+// for the IEEE division sequence (scale, refine, fmas, fixup); within an ulp, not correctly rounded.  The
+// tree-parallel kernels divide by pivots, impedances and curvatures that are bounded away from zero.
+__device__ __forceinline__ double tp_rcp(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  double e = fma(-x, y, 1.0);
+  y = fma(y, e, y);
+  e = fma(-x, y, 1.0);
+  return fma(y, e, y);
+}
 // ---- cross-lane primitives.  `sa` arguments are ds_bpermute byte addresses (lane * 4).
 __device__ __forceinline__ double bperm(double v, int sa) {
   const int lo = __builtin_amdgcn_ds_bpermute(sa, __double2loint(v));
@@ -173,7 +183,7 @@ __device__ __forceinline__ void tp_chain_sum(double* v, int par_sa, int rounds, 
 __device__ __forceinline__ void tp_chain_pose(V3& pos, Q4& quat, const V3& lp, const Q4& lq, int par_sa, int world_sa,
                                               int rounds, bool isb) {
   auto unit = [](Q4& q) {
-    const double inv = 1.0 / sqrt(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
+    const double inv = tp_rsqrt(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
     q.w *= inv; q.x *= inv; q.y *= inv; q.z *= inv;
   };
   pos = {0, 0, 0};
@@ -266,7 +276,7 @@ __device__ TP_HELPER_ATTR TpFac tp_factor(TpCtx c, TpRow Rin) {
     const bool is = c.dd == D;
     double T[TP_NPAIR];
     const double r0 = is ? R[0] : 1.0;
-    const double ir0 = 1.0 / r0;
+    const double ir0 = tp_rcp(r0);
 #pragma unroll
     for (int a = 1; a < TP_MAXD; a++) {
       if (a >= D) continue;
@@ -320,7 +330,7 @@ __device__ TP_HELPER_ATTR double tp_factor_solve(TpCtx c, TpRow Rin, double x) {
     const bool is = c.dd == D;
     double T[TP_NPAIR], S[TP_MAXD];
     const double r0 = is ? R[0] : 1.0;
-    const double ir0 = 1.0 / r0;
+    const double ir0 = tp_rcp(r0);
 #pragma unroll
     for (int a = 1; a < TP_MAXD; a++) {
       if (a >= D) continue;
@@ -388,7 +398,7 @@ __device__ TP_HELPER_ATTR void tp_factor2(TpCtx c, TpRow R0in, TpRow R1in, TpFac
 #pragma unroll
     for (int n = 0; n < 2; n++) {
       const double r0 = is ? R[n][0] : 1.0;
-      const double ir0 = 1.0 / r0;
+      const double ir0 = tp_rcp(r0);
 #pragma unroll
       for (int a = 1; a < TP_MAXD; a++) {
         if (a >= D) continue;
@@ -630,12 +640,20 @@ __host__ __device__ __forceinline__ double tp_impedance(const double* solimp, do
   const double dmin = fmin(fmax(solimp[0], BS_MINIMP), BS_MAXIMP), dmax = fmin(fmax(solimp[1], BS_MINIMP), BS_MAXIMP);
   const double width = fmax(solimp[2], BS_MINVAL), mid = fmin(fmax(solimp[3], BS_MINIMP), BS_MAXIMP);
   const double power = fmax(solimp[4], 1.0);
+#ifdef __HIP_DEVICE_COMPILE__
+  const double x = fabs(pos - margin) * tp_rcp(width);
+#else
   const double x = fabs(pos - margin) / width;
+#endif
   if (dmin == dmax || x >= 1.0) return (x >= 1.0) ? dmax : 0.5 * (dmin + dmax);
   if (x <= 0) return dmin;
   double y;
   if (power == 1.0) y = x;
+#ifdef __HIP_DEVICE_COMPILE__
+  else if (power == 2.0) y = (x <= mid) ? x * x * tp_rcp(mid) : 1 - (1 - x) * (1 - x) * tp_rcp(1 - mid);
+#else
   else if (power == 2.0) y = (x <= mid) ? x * x / mid : 1 - (1 - x) * (1 - x) / (1 - mid);
+#endif
   else if (x <= mid) y = pow(x, power) / pow(mid, power - 1);
   else y = 1 - pow(1 - x, power) / pow(1 - mid, power - 1);
   return dmin + y * (dmax - dmin);
@@ -731,7 +749,7 @@ __device__ __forceinline__ double tp_line_search(const DevModel& m, const TpRows
   int it = 0;
   const int maxit = m.ls_iterations;
   const TpLs p0 = tp_ls_eval<CON>(r, s, 0.0, gauss, g1, g2);
-  TpLs p1 = tp_ls_eval<CON>(r, s, p0.alpha - p0.d0 / p0.d1, gauss, g1, g2);
+  TpLs p1 = tp_ls_eval<CON>(r, s, p0.alpha - p0.d0 * tp_rcp(p0.d1), gauss, g1, g2);
   if (p0.cost < p1.cost) p1 = p0;
   if (fabs(p1.d0) < gtol) return p1.alpha;
   const double dir = p1.d0 < 0 ? 1.0 : -1.0;
@@ -739,13 +757,13 @@ __device__ __forceinline__ double tp_line_search(const DevModel& m, const TpRows
   TpLs p2 = p1;
   while (p1.d0 * dir <= -gtol && it < maxit) {
     p2 = p1; p2update = true;
-    p1 = tp_ls_eval<CON>(r, s, p1.alpha - p1.d0 / p1.d1, gauss, g1, g2);
+    p1 = tp_ls_eval<CON>(r, s, p1.alpha - p1.d0 * tp_rcp(p1.d1), gauss, g1, g2);
     it++;
     if (fabs(p1.d0) < gtol) return p1.alpha;
   }
   if (it >= maxit || !p2update) return p1.alpha;
   TpLs p2next = p1;
-  TpLs p1next = tp_ls_eval<CON>(r, s, p1.alpha - p1.d0 / p1.d1, gauss, g1, g2);
+  TpLs p1next = tp_ls_eval<CON>(r, s, p1.alpha - p1.d0 * tp_rcp(p1.d1), gauss, g1, g2);
   while (it < maxit) {
     const TpLs pmid = tp_ls_eval<CON>(r, s, 0.5 * (p1.alpha + p2.alpha), gauss, g1, g2);
     it++;
@@ -761,8 +779,8 @@ __device__ __forceinline__ double tp_line_search(const DevModel& m, const TpRows
       }
     }
     if (!b1 && !b2) break;
-    if (b1) p1next = tp_ls_eval<CON>(r, s, p1.alpha - p1.d0 / p1.d1, gauss, g1, g2);
-    if (b2) p2next = tp_ls_eval<CON>(r, s, p2.alpha - p2.d0 / p2.d1, gauss, g1, g2);
+    if (b1) p1next = tp_ls_eval<CON>(r, s, p1.alpha - p1.d0 * tp_rcp(p1.d1), gauss, g1, g2);
+    if (b2) p2next = tp_ls_eval<CON>(r, s, p2.alpha - p2.d0 * tp_rcp(p2.d1), gauss, g1, g2);
   }
   const TpLs best = p1.cost <= p2.cost ? p1 : p2;
   return best.cost < p0.cost ? best.alpha : 0.0;
@@ -1042,7 +1060,7 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
   const double mass = isb ? m.body_mass[b] : 0.0, qpos0 = m.qpos0[j];
   const double damping = has_dof ? m.dof_damping[j] : 0.0;
   const double h = m.timestep;
-  const double scale = 1.0 / (m.meaninertia * (m.nv > 1 ? m.nv : 1));
+  const double scale = tp_rcp(m.meaninertia * (m.nv > 1 ? m.nv : 1));
 
   // state
   double qpos = has_dof ? AT(d.qpos, j) : 0.0, qvel = has_dof ? AT(d.qvel, j) : 0.0;
@@ -1126,7 +1144,7 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
         const double rx = bperm(xipos.x, ra), ry = bperm(xipos.y, ra), rz = bperm(xipos.z, ra);
         if (mine) {
           if (sm < BS_MINVAL) com = {rx, ry, rz};
-          else com = {sx / sm, sy / sm, sz / sm};
+          else { const double ism = tp_rcp(sm); com = {sx * ism, sy * ism, sz * ism}; }
         }
       }
       double cinert[10], cdof[6];
@@ -1419,9 +1437,9 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
           if (dist < margin) {
             const double mu = pc[1], K = pc[2], B = pc[3];
             const double imp = tp_impedance(pc + 4, dist, margin);
-            double R = fmax(BS_MINVAL, (1 - imp) * pc[9] / imp);
+            double R = fmax(BS_MINVAL, (1 - imp) * pc[9] * tp_rcp(imp));
             if (dim > 1) R = fmax(BS_MINVAL, pc[10] * R);
-            cnr = dim == 1 ? 1 : 4; cmu = dim == 1 ? 0.0 : mu; cDrow = 1.0 / R;
+            cnr = dim == 1 ? 1 : 4; cmu = dim == 1 ? 0.0 : mu; cDrow = tp_rcp(R);
             myslot[CG_D] = cDrow; myslot[CG_MU] = cmu;
             cB = B; ckimp = K * imp * (dist - margin);
           }
@@ -1466,13 +1484,13 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
           const double d0 = qpos - lk[TPK_JRANGE], d1 = lk[TPK_JRANGE + 1] - qpos;
           if (d0 < margin) {
             const double imp = tp_impedance(lk + TPK_JSOLIMP, d0, margin);
-            r.Dl0 = 1.0 / fmax(BS_MINVAL, (1 - imp) * iw / imp);
+            r.Dl0 = tp_rcp(fmax(BS_MINVAL, (1 - imp) * iw * tp_rcp(imp)));
             r.aref_l0 = -B * qvel - K * imp * (d0 - margin);
             nact++;
           }
           if (d1 < margin) {
             const double imp = tp_impedance(lk + TPK_JSOLIMP, d1, margin);
-            r.Dl1 = 1.0 / fmax(BS_MINVAL, (1 - imp) * iw / imp);
+            r.Dl1 = tp_rcp(fmax(BS_MINVAL, (1 - imp) * iw * tp_rcp(imp)));
             r.aref_l1 = B * qvel - K * imp * (d1 - margin);
             nact++;
           }
@@ -1488,7 +1506,7 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
           const double deriv = cf[1] + x * (2 * cf[2] + x * (3 * cf[3] + x * 4 * cf[4]));
           const double diag = rc[TPD_EQ_DIAG], K = rc[TPD_EQ_K], B = rc[TPD_EQ_B];
           const double imp = tp_impedance(lk + TPK_EQSOLIMP, pos_e, 0.0);
-          r.own = true; r.ce = deriv; r.De = 1.0 / fmax(BS_MINVAL, (1 - imp) * diag / imp);
+          r.own = true; r.ce = deriv; r.De = tp_rcp(fmax(BS_MINVAL, (1 - imp) * diag * tp_rcp(imp)));
           r.aref_e = -B * (qvel - deriv * vo) - K * imp * pos_e;
           nact++;
         }
