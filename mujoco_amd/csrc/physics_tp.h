@@ -1755,9 +1755,9 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
         const tp_lds_d Orow = Minv + ko * mstride;
         // (M^-1 J_r^T)_l for the row kinds, J_r (M^-1 J_r^T) + 1/D on the owner lane
         const double mjj = has_dof ? Mrow[l] : 0.0;
-        const double ARf = mjj + (r.Df > 0 ? 1.0 / r.Df : 0.0), AR0 = mjj + (r.Dl0 > 0 ? 1.0 / r.Dl0 : 0.0),
-                     AR1 = mjj + (r.Dl1 > 0 ? 1.0 / r.Dl1 : 0.0);
-        const double ARe = r.own ? (Mrow[l] - r.ce * Mrow[ko]) - r.ce * (Orow[l] - r.ce * Orow[ko]) + 1.0 / r.De : 1.0;
+        const double ARf = mjj + (r.Df > 0 ? tp_rcp(r.Df) : 0.0), AR0 = mjj + (r.Dl0 > 0 ? tp_rcp(r.Dl0) : 0.0),
+                     AR1 = mjj + (r.Dl1 > 0 ? tp_rcp(r.Dl1) : 0.0);
+        const double ARe = r.own ? (Mrow[l] - r.ce * Mrow[ko]) - r.ce * (Orow[l] - r.ce * Orow[ko]) + tp_rcp(r.De) : 1.0;
         // ---- contacts (k_tpc_pgs): U_c = Jacobian rows (normal, tangent1, tangent2) of contact c, one
         // entry per dof lane, recomputed from the lane's motion axis where needed; w_q = M^-1 U_c[q]^T
         // through the M^-1 rows in LDS; the 3x3 block B_c = U_c M^-1 U_c^T is formed once per step and
@@ -1871,9 +1871,9 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
         int iter = 0;
         TPC_T(21)
         // reciprocals of D and of the diagonal of A + R once per step (the sweep is a latency chain)
-        const double iDf = r.Df > 0 ? 1.0 / r.Df : 0.0, iD0 = r.Dl0 > 0 ? 1.0 / r.Dl0 : 0.0, iD1 = r.Dl1 > 0 ? 1.0 / r.Dl1 : 0.0,
-                     iDe = r.own ? 1.0 / r.De : 0.0;
-        const double iARf = 1.0 / ARf, iAR0 = 1.0 / AR0, iAR1 = 1.0 / AR1, iARe = 1.0 / ARe;
+        const double iDf = r.Df > 0 ? tp_rcp(r.Df) : 0.0, iD0 = r.Dl0 > 0 ? tp_rcp(r.Dl0) : 0.0, iD1 = r.Dl1 > 0 ? tp_rcp(r.Dl1) : 0.0,
+                     iDe = r.own ? tp_rcp(r.De) : 0.0;
+        const double iARf = tp_rcp(ARf), iAR0 = tp_rcp(AR0), iAR1 = tp_rcp(AR1), iARe = tp_rcp(ARe);
         // one row: the owner lane ol projects its force, everybody applies the change.  kind is
         // uniform over the wavefront, ol over the environment.
         auto row = [&](int kind, int ol, double& improvement) {
@@ -1936,7 +1936,7 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
               double jn = env_sum(u0 * acc), j1 = env_sum(u1 * acc), j2 = env_sum(u2 * acc);
               con_w(u0, u1, u2, chain, w0, w1, w2);
               if (act) {
-                const double Dc = sl[CG_D], muc = sl[CG_MU], iDc = 1.0 / Dc;
+                const double Dc = sl[CG_D], muc = sl[CG_MU], iDc = tp_rcp(Dc);
                 const double bnn = sl[CG_B], bn1 = sl[CG_B + 1], bn2 = sl[CG_B + 2], b11 = sl[CG_B + 3], b12 = sl[CG_B + 4],
                              b22 = sl[CG_B + 5];
                 double dn = 0, d1 = 0, d2 = 0;
@@ -1950,7 +1950,7 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
                   const double ARii = gn + s1 * g1 + s2 * g2 + iDc;
                   const double old = sl[CG_F + q];
                   const double res = (jn + s1 * j1 + s2 * j2) - sl[CG_AREF + q] + old * iDc;
-                  double f = old - res / ARii;
+                  double f = old - res * tp_rcp(ARii);
                   if (f < 0) f = 0;
                   double delta = f - old, change = 0.5 * delta * delta * ARii + delta * res;
                   if (change > 1e-10) { f = old; delta = 0; change = 0; }
