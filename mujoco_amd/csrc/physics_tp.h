@@ -694,6 +694,11 @@ struct TpLs { double alpha, cost, d0, d1; };
 template <bool CON>
 __device__ TP_HELPER_ATTR TpLs tp_ls_eval(TpRows r, TpSol s, double alpha, double g0, double g1, double g2) {
   double q0 = 0, q1 = 0, q2 = 0;
+  // J * search of the lane's rows made opaque per evaluation: otherwise the curvature terms 0.5 D v^2 (they do not
+  // depend on alpha) are hoisted out of the inlined evaluations, spilled, and reloaded from scratch inside each one —
+  // a dependent round trip to memory for two multiplications
+  asm volatile("" : "+v"(s.vf), "+v"(s.ve), "+v"(s.vl0), "+v"(s.vl1));
+  if constexpr (CON) asm volatile("" : "+v"(s.cv[0]), "+v"(s.cv[1]), "+v"(s.cv[2]), "+v"(s.cv[3]));
   if constexpr (CON) {
 #pragma unroll
     // one-sided rows without selects on q0 / q1: min(x, 0) contributes the same products when the row is
