@@ -88,7 +88,13 @@ struct TpModel {
 
 // sincos out of line: inlined into the step loop, its polynomial coefficients are hoisted out of the loop as
 // register pairs, spilled, and reloaded from scratch one dependent round trip at a time inside every call
-__device__ __attribute__((noinline)) void tp_sincos(double x, double* sn, double* cs) { sincos(x, sn, cs); }
+// (results by value: through pointers they went out by a store to and a load from scratch on every call)
+struct TpSinCos { double sn, cs; };
+__device__ __attribute__((noinline)) TpSinCos tp_sincos(double x) {
+  TpSinCos r;
+  sincos(x, &r.sn, &r.cs);
+  return r;
+}
 // 1 / sqrt(x) for x in the normal range: v_rsq_f64 refined by three Goldschmidt rounds (the last one for h only),
 // 12 VALU instructions against ~40 for an IEEE sqrt followed by an IEEE division; within an ulp or two, not
 // correctly rounded.  For the pivots of k_tpc's dense Cholesky (24 of them per Newton iteration).
@@ -1105,8 +1111,8 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
           const V3 s = mrot(q2m(bquat), jax);
           lp = {bpos.x + s.x * dq, bpos.y + s.y * dq, bpos.z + s.z * dq};
         } else {
-          double sn, cs;
-          tp_sincos(0.5 * dq, &sn, &cs);
+          const TpSinCos sc = tp_sincos(0.5 * dq);
+          const double sn = sc.sn, cs = sc.cs;
           const Q4 qj = {cs, jax.x * sn, jax.y * sn, jax.z * sn};
           lq = qmul(bquat, qj);
           const V3 rj = mrot(q2m(qj), jpos);
