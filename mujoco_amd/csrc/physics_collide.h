@@ -74,7 +74,16 @@ __host__ __device__ inline int dir_bin(double x, double y, double z) {
   else if (ay >= az) { face = y < 0 ? 3 : 2; w = ay; u = x; v = z; }
   else { face = z < 0 ? 5 : 4; w = az; u = x; v = y; }
   if (!(w > 0)) return 0;
+#ifdef __HIP_DEVICE_COMPILE__
+  // any bin is a valid start for the climb, so the device divides by reciprocal (one v_rcp_f64 + two Newton steps
+  // for both quotients instead of two IEEE division sequences per support call and hull)
+  double iw = __builtin_amdgcn_rcp(w);
+  iw = fma(fma(-w, iw, 1.0), iw, iw);
+  iw = fma(fma(-w, iw, 1.0), iw, iw);
+  int iu = (int)((u * iw * 0.5 + 0.5) * BS_SG), iv = (int)((v * iw * 0.5 + 0.5) * BS_SG);
+#else
   int iu = (int)((u / w * 0.5 + 0.5) * BS_SG), iv = (int)((v / w * 0.5 + 0.5) * BS_SG);
+#endif
   iu = iu < 0 ? 0 : (iu >= BS_SG ? BS_SG - 1 : iu);
   iv = iv < 0 ? 0 : (iv >= BS_SG ? BS_SG - 1 : iv);
   return (face * BS_SG + iu) * BS_SG + iv;
@@ -136,8 +145,24 @@ __device__ __forceinline__ double dot(const V3& a, const V3& b) { return a.x * b
 __device__ __forceinline__ V3 sub(const V3& a, const V3& b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
 __device__ __forceinline__ V3 sub3(const V3& a, const V3& b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
 __device__ __forceinline__ V3 neg(const V3& a) { return {-a.x, -a.y, -a.z}; }
+// a / |a|: v_rsq_f64 refined by Goldschmidt rounds and three multiplications (12 + 3 VALU instructions; the IEEE
+// sqrt and three IEEE divisions were ~100, and MPR normalises a direction or two per portal step).  Within an ulp
+// or two of the IEEE quotient; squared lengths outside the normal range take the IEEE path.
 __device__ __forceinline__ V3 normalized(const V3& a) {
-  const double n = sqrt(dot(a, a));
+  const double d = dot(a, a);
+  if (d > 1e-280 && d < 1e280) {
+    const double y = __builtin_amdgcn_rsq(d);
+    double g = d * y, h = 0.5 * y;
+    double r = fma(-h, g, 0.5);
+    g = fma(g, r, g); h = fma(h, r, h);
+    r = fma(-h, g, 0.5);
+    g = fma(g, r, g); h = fma(h, r, h);
+    r = fma(-h, g, 0.5);
+    h = fma(h, r, h);
+    const double inv = h + h;
+    return {a.x * inv, a.y * inv, a.z * inv};
+  }
+  const double n = sqrt(d);
   if (n > 0) return {a.x / n, a.y / n, a.z / n};
   return a;
 }
