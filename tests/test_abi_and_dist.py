@@ -48,6 +48,14 @@ def test_model_desc_validation_without_gpu(hand_model):
     bad.opt_timestep = 0.0
     with pytest.raises(_abi.BatchSimError, match="timestep"):
         NativeModel(bad)
+    # the per-pair collision records hold 12-bit geom ids: 4096 geoms and up are refused with a message
+    from mujoco_amd import load_model_from_xml
+    spheres = "".join(f'<geom type="sphere" size="0.001" pos="{0.01 * (i % 64)} {0.01 * (i // 64)} 0.1"/>' for i in range(4100))
+    big = load_model_from_xml('<mujoco><worldbody><geom type="plane" size="5 5 0.1"/><body><joint type="hinge" axis="0 0 1"/>'
+                              + spheres + "</body></worldbody></mujoco>")
+    assert big.ngeom > 4095 and big.npair > 0
+    with pytest.raises(_abi.BatchSimError, match="12-bit"):
+        NativeModel(big)
     h = C.c_void_p()
     assert _abi.lib().bs_model_create(None, C.byref(h)) == -1
     n = C.c_int(-1)
