@@ -838,6 +838,15 @@ __device__ inline void col_narrow_persistent(const ColModel& cm, const DevData& 
   const int lane = threadIdx.x & 63;
   const unsigned long long lower = (1ull << lane) - 1ull;
   unsigned cursor = first;  // wave-uniform
+  int sublist = 0;  // sub-list of the wavefront's first item (uniform), then of the lane's last item
+  {
+    int hi = BS_NSUB;
+    while (hi - sublist > 1) {
+      const int mid = (sublist + hi) >> 1;
+      if (pre[mid] <= first) sublist = mid;
+      else hi = mid;
+    }
+  }
   bool busy = false, plane = false;
   long e = 0;
   int slot = 0, iters = 0;
@@ -858,12 +867,10 @@ __device__ inline void col_narrow_persistent(const ColModel& cm, const DevData& 
       const unsigned i = cursor + (unsigned)__popcll(need & lower);
       cursor += (unsigned)__popcll(need);
       if (!busy && i < last) {
-        int lo = 0, hi = BS_NSUB;  // sub-list of item i: largest s with pre[s] <= i
-        while (hi - lo > 1) {
-          const int mid = (lo + hi) >> 1;
-          if (pre[mid] <= i) lo = mid;
-          else hi = mid;
-        }
+        // sub-list of item i: largest s with pre[s] <= i.  Items are handed out in increasing order, so a lane's
+        // sub-list never decreases and the search resumes where its last one ended (a step or none, not six)
+        while (pre[sublist + 1] <= i) sublist++;  // i < last <= pre[BS_NSUB]
+        const int lo = sublist;
         const int it = items[lo * subcap + (i - pre[lo])];
         e = d.env0 + (it >> 8); slot = it & 255;
         const int p = (c.crec ? c.crec[(size_t)e * cm.maxcand + slot].pair : AT(c.cand_pair, slot)) & BS_PAIR_MASK;
