@@ -145,6 +145,19 @@ static void build_tp(bs_model* m) {
       }
     }
   }
+  // levels whose bodies (two or more) all hang off one body
+  for (int L = 0; L < 34; L++) m->tp.lvl_parent[L] = -1;
+  for (int L = 2; L <= maxdepth && L < 34; L++) {
+    int par = -1, cnt = 0;
+    bool one = true;
+    for (int b = 1; b < nb; b++)
+      if (depth[b] == L) {
+        cnt++;
+        if (par < 0) par = s.body_parentid[b];
+        else if (par != s.body_parentid[b]) one = false;
+      }
+    if (one && cnt >= 2 && par > 0) m->tp.lvl_parent[L] = par;
+  }
   // equalities: owner = dof1's lane, other = dof2 (must be an ancestor dof of dof1)
   for (size_t r = 0; r < m->eq_dof1.size(); r++) {
     const int d1 = m->eq_dof1[r], d2 = m->eq_dof2[r];

@@ -83,6 +83,7 @@ struct TpModel {
   int npgs;
   int roots[4];
   int lvl_bchild[34];          // max #children over bodies at depth L-1, indexed by child depth L
+  int lvl_parent[34];          // >= 0: every body at depth L (two or more) is a child of this one body: its fold is a reduction over the lanes
   int lvl_dchild[TP_MAXD + 2]; // max #dof-children over dofs with dd == D-1, indexed by D
 };
 
@@ -1234,6 +1235,17 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
         for (int k = 0; k < 10; k++) crb[k] = cinert[k];
         for (int lvl = t.maxdepth; lvl >= (FULL ? 2 : t.fold_minlvl); lvl--) {
           const bool par = isb && depth == lvl - 1;
+          if (!CON && t.lvl_parent[lvl] >= 0) {
+            // all bodies of this level hang off one body (a palm and its fingers): their sum is a reduction over the
+            // environment's lanes (DPP, VALU rate) instead of one ds_bpermute round per child — the contact-free
+            // kernels are bound by the CU's LDS pipe in this section.  Contact kernels keep the rounds (fewer VALU).
+            const bool kid = isb && depth == lvl, top = l == t.lvl_parent[lvl];
+#pragma unroll
+            for (int k = 0; k < 10; k++) { const double sk = env_sum(kid ? crb[k] : 0.0); if (top) crb[k] += sk; }
+#pragma unroll
+            for (int k = 0; k < 6; k++) { const double sk = env_sum(kid ? f[k] : 0.0); if (top) f[k] += sk; }
+            continue;
+          }
           for (int ch = 0; ch < t.lvl_bchild[lvl]; ch++) {
             const int src = ch == 0 ? bchild0 : tp_child(c.tbl, TPL_BCHILD, ch);
             const int sa = par ? src : c.zero_sa;
