@@ -1235,10 +1235,10 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
         for (int k = 0; k < 10; k++) crb[k] = cinert[k];
         for (int lvl = t.maxdepth; lvl >= (FULL ? 2 : t.fold_minlvl); lvl--) {
           const bool par = isb && depth == lvl - 1;
-          if (!CON && t.lvl_parent[lvl] >= 0) {
+          if (t.lvl_parent[lvl] >= 0) {
             // all bodies of this level hang off one body (a palm and its fingers): their sum is a reduction over the
             // environment's lanes (DPP, VALU rate) instead of one ds_bpermute round per child — the contact-free
-            // kernels are bound by the CU's LDS pipe in this section.  Contact kernels keep the rounds (fewer VALU).
+            // kernels are bound by the CU's LDS pipe in this section (the contact kernels neither gain nor lose).
             const bool kid = isb && depth == lvl, top = l == t.lvl_parent[lvl];
 #pragma unroll
             for (int k = 0; k < 10; k++) { const double sk = env_sum(kid ? crb[k] : 0.0); if (top) crb[k] += sk; }
