@@ -145,6 +145,14 @@ static void build_tp(bs_model* m) {
       }
     }
   }
+  // levels whose bodies all sit on the lane after their parent's
+  for (int L = 0; L < 34; L++) m->tp.lvl_next[L] = 0;
+  for (int L = 2; L <= maxdepth && L < 34; L++) {
+    bool all = true, any = false;
+    for (int b = 1; b < nb; b++)
+      if (depth[b] == L) { any = true; if (s.body_parentid[b] != b - 1) all = false; }
+    m->tp.lvl_next[L] = any && all;
+  }
   // levels whose bodies (two or more) all hang off one body
   for (int L = 0; L < 34; L++) m->tp.lvl_parent[L] = -1;
   for (int L = 2; L <= maxdepth && L < 34; L++) {

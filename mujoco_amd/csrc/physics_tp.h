@@ -83,6 +83,7 @@ struct TpModel {
   int npgs;
   int roots[4];
   int lvl_bchild[34];          // max #children over bodies at depth L-1, indexed by child depth L
+  int lvl_next[34];            // 1: every body at depth L is the lane after its parent (chains in depth-first order): the fold is a DPP shift
   int lvl_parent[34];          // >= 0: every body at depth L (two or more) is a child of this one body: its fold is a reduction over the lanes
   int lvl_dchild[TP_MAXD + 2]; // max #dof-children over dofs with dd == D-1, indexed by D
 };
@@ -1244,6 +1245,16 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
             for (int k = 0; k < 10; k++) { const double sk = env_sum(kid ? crb[k] : 0.0); if (top) crb[k] += sk; }
 #pragma unroll
             for (int k = 0; k < 6; k++) { const double sk = env_sum(kid ? f[k] : 0.0); if (top) f[k] += sk; }
+            continue;
+          }
+          if (t.lvl_next[lvl]) {
+            // every body of this level sits on the lane after its parent's (single-child chains numbered depth-first):
+            // the parent takes its child's values with a wavefront shift (DPP wave_shl:1), no LDS-pipe instruction
+            const bool recv = par && bchild0 == self_sa + 4;
+#pragma unroll
+            for (int k = 0; k < 10; k++) { const double v = dpp_mov<0x130>(crb[k]); if (recv) crb[k] += v; }
+#pragma unroll
+            for (int k = 0; k < 6; k++) { const double v = dpp_mov<0x130>(f[k]); if (recv) f[k] += v; }
             continue;
           }
           for (int ch = 0; ch < t.lvl_bchild[lvl]; ch++) {
