@@ -145,6 +145,11 @@ static void build_tp(bs_model* m) {
       }
     }
   }
+  // dofs below the first branching as single-child chains on consecutive lanes (k_tp_chain)
+  m->tp.chain = maxdd >= 3;
+  for (int j = 0; j < nv; j++)
+    if (dd[j] >= 3 && s.dof_bodyid[s.dof_parentid[j]] != s.dof_bodyid[j] - 1) m->tp.chain = 0;
+  if (getenv("BS_NO_CHAIN")) m->tp.chain = 0;
   // levels whose bodies all sit on the lane after their parent's
   for (int L = 0; L < 34; L++) m->tp.lvl_next[L] = 0;
   for (int L = 2; L <= maxdepth && L < 34; L++) {
@@ -964,7 +969,8 @@ static void launch_step(bs_sim* s, int n_steps) {
   if (s->use_tp) {
     const bool rk = s->dm.integrator == 1;
     auto* launch = s->dm.solver == 0 ? (rk ? bs_launch_tp_rk4_pgs : bs_launch_tp_pgs)
-                   : s->dm.solver == 1 ? (rk ? bs_launch_tp_rk4_cg : bs_launch_tp_cg) : (rk ? bs_launch_tp_rk4 : bs_launch_tp);
+                   : s->dm.solver == 1 ? (rk ? bs_launch_tp_rk4_cg : bs_launch_tp_cg)
+                                       : (rk ? bs_launch_tp_rk4 : (s->tp.chain ? bs_launch_tp_chain : bs_launch_tp));
     int dump = 1;
 #ifdef TPC_CUTS
     if (const char* e = getenv("BS_CUT")) dump |= (atoi(e) + 1) << 8;

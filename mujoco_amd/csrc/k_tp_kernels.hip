@@ -7,7 +7,8 @@
 #define TP_OCC 2
 #endif
 
-#define TP_KERNEL(name, CONTACTS_, FULL_, RK4_, CG_, PGS_, PARK_, MINV_)                                              \
+#define TP_KERNEL(name, CONTACTS_, FULL_, RK4_, CG_, PGS_, PARK_, MINV_) TP_KERNEL_C(name, CONTACTS_, FULL_, RK4_, CG_, PGS_, PARK_, MINV_, false)
+#define TP_KERNEL_C(name, CONTACTS_, FULL_, RK4_, CG_, PGS_, PARK_, MINV_, CHAIN_)                                   \
   __global__ __launch_bounds__(64, TP_OCC) void k_##name(DevModel m, TpModel t, DevData d, int nsteps, int mode, int dump) { \
     __shared__ int tbl[TPL_TOTAL * 64];                                                                               \
     __shared__ double park[PARK_ ? (TP_MAXD + 1) * 64 : 1];                                                           \
@@ -15,7 +16,7 @@
     const TpShared sh = {tbl, nullptr, nullptr, nullptr, PARK_ ? park : nullptr, MINV_ ? minv : nullptr};             \
     ColModel cm;                                                                                                      \
     ColData cd;                                                                                                       \
-    tp_run<CONTACTS_, FULL_, RK4_, CG_, PGS_>(m, t, d, nsteps, mode, dump, sh, cm, cd);                               \
+    tp_run<CONTACTS_, FULL_, RK4_, CG_, PGS_, CHAIN_>(m, t, d, nsteps, mode, dump, sh, cm, cd);                       \
   }                                                                                                                   \
   void bs_launch_##name(BS_TP_ARGS) { hipLaunchKernelGGL(k_##name, g, dim3(64), lds, st, m, t, d, nsteps, mode, dump); }
 
@@ -35,6 +36,10 @@
 
 #if defined(TPK_tp)
 TP_KERNEL(tp, false, false, false, false, false, true, false)
+#elif defined(TPK_tp_chain)
+// Euler + Newton, contact-free, for models whose dofs below the first branching form single-child chains on
+// consecutive lanes (TpModel::chain): the sweeps' packets of those levels move by DPP shifts
+TP_KERNEL_C(tp_chain, false, false, false, false, false, true, false, true)
 #elif defined(TPK_tp_cg)
 TP_KERNEL(tp_cg, false, false, false, true, false, true, false)
 #elif defined(TPK_tp_pgs)

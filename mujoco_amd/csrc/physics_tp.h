@@ -86,6 +86,7 @@ struct TpModel {
   int lvl_next[34];            // 1: every body at depth L is the lane after its parent (chains in depth-first order): the fold is a DPP shift
   int lvl_parent[34];          // >= 0: every body at depth L (two or more) is a child of this one body: its fold is a reduction over the lanes
   int lvl_dchild[TP_MAXD + 2]; // max #dof-children over dofs with dd == D-1, indexed by D
+  int chain;                   // 1: every dof with dd >= 3 is on the lane after its parent dof's (the CHAIN kernels apply)
 };
 
 // sincos out of line: inlined into the step loop, its polynomial coefficients are hoisted out of the loop as
@@ -268,10 +269,23 @@ __device__ __forceinline__ int tp_child(tp_lds_ptr tbl, int row0, int ch) {
   return ((w >> (((ch - 1) & 3) * 8)) & 0xff) << 2;
 }
 
+// what a parent dof receives from its child in a leaves-to-root sweep: a ds_bpermute per value, or — in the CHAIN
+// instantiation, on the levels below the first branching (TpModel::chain: every dof of level D >= 3 sits on the lane
+// after its parent dof's, single-child chains numbered depth-first) — a DPP wavefront shift, which keeps the
+// sweeps' packets off the CU's LDS pipe.  Compile-time per level: a run-time choice doubled the sweeps' code and
+// register pressure (scratch 96 -> 280 B) and lost more than the shifts won.
+__device__ __forceinline__ double tp_up(double x, int sa, bool shift, bool recv) {
+  if (shift) {  // constant once the level loop is unrolled
+    const double v = dpp_mov<0x130>(x);  // wave_shl:1: lane l reads lane l + 1
+    return recv ? v : 0.0;
+  }
+  return bperm(x, sa);
+}
 // sparse L^T D L of the distributed rows (mj_factorM layout): R[0] diagonal, R[a] the entry with
 // the a-th ancestor dof.  Level by level from the leaves: a finished dof sends the outer-product
 // packet T(a,b) = L(k,a) M(k,b) + (packets forwarded from below) to its parent, which applies the
 // (1,b) entries to its own row and forwards the rest one position up.
+template <bool CHAIN = false>
 __device__ TP_HELPER_ATTR TpFac tp_factor(TpCtx c, TpRow Rin) {
   double* R = Rin.r;
   double A[TP_NPAIR];
@@ -299,7 +313,8 @@ __device__ TP_HELPER_ATTR TpFac tp_factor(TpCtx c, TpRow Rin) {
     if (is) dinv = ir0;
     if (D == 1) break;
     const bool par = c.dd == D - 1;
-    for (int ch = 0; ch < c.nchild[D]; ch++) {
+    const bool recv = par && c.dchild0 == c.self_sa + 4;  // CHAIN: the child dof is on the next lane
+    for (int ch = 0; ch < (CHAIN && D >= 3 ? 1 : c.nchild[D]); ch++) {
       const int src = ch == 0 ? c.dchild0 : tp_child(c.tbl, TPL_DCHILD, ch);
       const int sa = par ? src : c.zero_sa;
 #pragma unroll
@@ -308,7 +323,7 @@ __device__ TP_HELPER_ATTR TpFac tp_factor(TpCtx c, TpRow Rin) {
 #pragma unroll
         for (int b = a; b < TP_MAXD; b++) {
           if (b >= D) continue;
-          const double v = bperm(T[pair_idx(a, b)], sa);
+          const double v = tp_up(T[pair_idx(a, b)], sa, CHAIN && D >= 3, recv);
           if (a == 1) R[b - 1] -= v;
           else A[pair_idx(a - 1, b - 1)] += v;
         }
@@ -324,6 +339,7 @@ __device__ TP_HELPER_ATTR TpFac tp_factor(TpCtx c, TpRow Rin) {
 
 // tp_factor followed by tp_solve with the same matrix, in one leaves-to-root pass: when the rows of
 // level D are final, their part of the forward substitution is sent up in the same exchange
+template <bool CHAIN = false>
 __device__ TP_HELPER_ATTR double tp_factor_solve(TpCtx c, TpRow Rin, double x) {
   double* R = Rin.r;
   double A[TP_NPAIR], W[TP_MAXD];
@@ -354,19 +370,20 @@ __device__ TP_HELPER_ATTR double tp_factor_solve(TpCtx c, TpRow Rin, double x) {
     if (is) dinv = ir0;
     if (D == 1) break;
     const bool par = c.dd == D - 1;
-    for (int ch = 0; ch < c.nchild[D]; ch++) {
+    const bool recv = par && c.dchild0 == c.self_sa + 4;  // CHAIN: the child dof is on the next lane
+    for (int ch = 0; ch < (CHAIN && D >= 3 ? 1 : c.nchild[D]); ch++) {
       const int src = ch == 0 ? c.dchild0 : tp_child(c.tbl, TPL_DCHILD, ch);
       const int sa = par ? src : c.zero_sa;
 #pragma unroll
       for (int a = 1; a < TP_MAXD; a++) {
         if (a >= D) continue;
-        const double sv = bperm(S[a], sa);
+        const double sv = tp_up(S[a], sa, CHAIN && D >= 3, recv);
         if (a == 1) x -= sv;
         else W[a - 1] += sv;
 #pragma unroll
         for (int b = a; b < TP_MAXD; b++) {
           if (b >= D) continue;
-          const double v = bperm(T[pair_idx(a, b)], sa);
+          const double v = tp_up(T[pair_idx(a, b)], sa, CHAIN && D >= 3, recv);
           if (a == 1) R[b - 1] -= v;
           else A[pair_idx(a - 1, b - 1)] += v;
         }
@@ -390,6 +407,7 @@ __device__ TP_HELPER_ATTR double tp_factor_solve(TpCtx c, TpRow Rin, double x) {
 
 // two factorisations with the same sparsity at once (M and M + h * damping): the level loop and its
 // cross-lane round trips are shared, so the second factor costs issue slots, not latency
+template <bool CHAIN = false>
 __device__ TP_HELPER_ATTR void tp_factor2(TpCtx c, TpRow R0in, TpRow R1in, TpFac& out0, TpFac& out1) {
   double* R[2] = {R0in.r, R1in.r};
   double A[2][TP_NPAIR];
@@ -422,7 +440,8 @@ __device__ TP_HELPER_ATTR void tp_factor2(TpCtx c, TpRow R0in, TpRow R1in, TpFac
     }
     if (D == 1) break;
     const bool par = c.dd == D - 1;
-    for (int ch = 0; ch < c.nchild[D]; ch++) {
+    const bool recv = par && c.dchild0 == c.self_sa + 4;  // CHAIN: the child dof is on the next lane
+    for (int ch = 0; ch < (CHAIN && D >= 3 ? 1 : c.nchild[D]); ch++) {
       const int src = ch == 0 ? c.dchild0 : tp_child(c.tbl, TPL_DCHILD, ch);
       const int sa = par ? src : c.zero_sa;
 #pragma unroll
@@ -433,7 +452,7 @@ __device__ TP_HELPER_ATTR void tp_factor2(TpCtx c, TpRow R0in, TpRow R1in, TpFac
           if (b >= D) continue;
 #pragma unroll
           for (int n = 0; n < 2; n++) {
-            const double v = bperm(T[n][pair_idx(a, b)], sa);
+            const double v = tp_up(T[n][pair_idx(a, b)], sa, CHAIN && D >= 3, recv);
             if (a == 1) R[n][b - 1] -= v;
             else A[n][pair_idx(a - 1, b - 1)] += v;
           }
@@ -447,6 +466,7 @@ __device__ TP_HELPER_ATTR void tp_factor2(TpCtx c, TpRow R0in, TpRow R1in, TpFac
 }
 
 // x <- (L^T D L)^-1 x (mj_solveM): leaves-to-root sweep, diagonal scale, root-to-leaves sweep
+template <bool CHAIN = false>
 __device__ TP_HELPER_ATTR double tp_solve(TpCtx c, TpRow Rin, double dinv, double x) {
   const double* R = Rin.r;
   double W[TP_MAXD];
@@ -456,17 +476,18 @@ __device__ TP_HELPER_ATTR double tp_solve(TpCtx c, TpRow Rin, double dinv, doubl
   for (int D = TP_MAXD; D >= 2; D--) {
     if (D > c.maxdd) continue;
     const bool is = c.dd == D, par = c.dd == D - 1;
+    const bool recv = par && c.dchild0 == c.self_sa + 4;  // CHAIN: the child dof is on the next lane
     double T[TP_MAXD];
 #pragma unroll
     for (int a = 1; a < TP_MAXD; a++)
       if (a < D) T[a] = is ? R[a] * x + W[a] : 0.0;
-    for (int ch = 0; ch < c.nchild[D]; ch++) {
+    for (int ch = 0; ch < (CHAIN && D >= 3 ? 1 : c.nchild[D]); ch++) {
       const int src = ch == 0 ? c.dchild0 : tp_child(c.tbl, TPL_DCHILD, ch);
       const int sa = par ? src : c.zero_sa;
 #pragma unroll
       for (int a = 1; a < TP_MAXD; a++) {
         if (a >= D) continue;
-        const double v = bperm(T[a], sa);
+        const double v = tp_up(T[a], sa, CHAIN && D >= 3, recv);
         if (a == 1) x -= v;
         else W[a - 1] += v;
       }
@@ -489,6 +510,7 @@ __device__ TP_HELPER_ATTR double tp_solve(TpCtx c, TpRow Rin, double dinv, doubl
 
 // tp_solve(R, dinv, x) and tp_mul_m(M, v) in one pass: the leaves-to-root sweeps of the two have the
 // same level loop, so the product rides along in the solve's cross-lane round trips
+template <bool CHAIN = false>
 __device__ TP_HELPER_ATTR double tp_solve_mulm(TpCtx c, TpRow Rin, double dinv, double x, TpRow Min, double v, double& mv) {
   const double* R = Rin.r;
   const double* Mr = Min.r;
@@ -506,17 +528,18 @@ __device__ TP_HELPER_ATTR double tp_solve_mulm(TpCtx c, TpRow Rin, double dinv, 
   for (int D = TP_MAXD; D >= 2; D--) {
     if (D > c.maxdd) continue;
     const bool is = c.dd == D, par = c.dd == D - 1;
+    const bool recv = par && c.dchild0 == c.self_sa + 4;  // CHAIN: the child dof is on the next lane
     double T[TP_MAXD], U[TP_MAXD];
 #pragma unroll
     for (int a = 1; a < TP_MAXD; a++)
       if (a < D) { T[a] = is ? R[a] * x + W[a] : 0.0; U[a] = is ? Mr[a] * v + V[a] : 0.0; }
-    for (int ch = 0; ch < c.nchild[D]; ch++) {
+    for (int ch = 0; ch < (CHAIN && D >= 3 ? 1 : c.nchild[D]); ch++) {
       const int src = ch == 0 ? c.dchild0 : tp_child(c.tbl, TPL_DCHILD, ch);
       const int sa = par ? src : c.zero_sa;
 #pragma unroll
       for (int a = 1; a < TP_MAXD; a++) {
         if (a >= D) continue;
-        const double t = bperm(T[a], sa), u = bperm(U[a], sa);
+        const double t = tp_up(T[a], sa, CHAIN && D >= 3, recv), u = tp_up(U[a], sa, CHAIN && D >= 3, recv);
         if (a == 1) { x -= t; res += u; }
         else { W[a - 1] += t; V[a - 1] += u; }
       }
@@ -539,7 +562,7 @@ __device__ TP_HELPER_ATTR double tp_solve_mulm(TpCtx c, TpRow Rin, double dinv, 
 }
 
 // N right-hand sides at once: the level sweeps and their cross-lane round trips are shared
-template <int N>
+template <int N, bool CHAIN = false>
 __device__ TP_HELPER_ATTR void tp_solve_n(TpCtx c, TpRow Rin, double dinv, double (&x)[N]) {
   const double* R = Rin.r;
   double W[N][TP_MAXD];
@@ -551,13 +574,14 @@ __device__ TP_HELPER_ATTR void tp_solve_n(TpCtx c, TpRow Rin, double dinv, doubl
   for (int D = TP_MAXD; D >= 2; D--) {
     if (D > c.maxdd) continue;
     const bool is = c.dd == D, par = c.dd == D - 1;
+    const bool recv = par && c.dchild0 == c.self_sa + 4;  // CHAIN: the child dof is on the next lane
     double T[N][TP_MAXD];
 #pragma unroll
     for (int n = 0; n < N; n++)
 #pragma unroll
       for (int a = 1; a < TP_MAXD; a++)
         if (a < D) T[n][a] = is ? R[a] * x[n] + W[n][a] : 0.0;
-    for (int ch = 0; ch < c.nchild[D]; ch++) {
+    for (int ch = 0; ch < (CHAIN && D >= 3 ? 1 : c.nchild[D]); ch++) {
       const int src = ch == 0 ? c.dchild0 : tp_child(c.tbl, TPL_DCHILD, ch);
       const int sa = par ? src : c.zero_sa;
 #pragma unroll
@@ -565,7 +589,7 @@ __device__ TP_HELPER_ATTR void tp_solve_n(TpCtx c, TpRow Rin, double dinv, doubl
         if (a >= D) continue;
 #pragma unroll
         for (int n = 0; n < N; n++) {
-          const double v = bperm(T[n][a], sa);
+          const double v = tp_up(T[n][a], sa, CHAIN && D >= 3, recv);
           if (a == 1) x[n] -= v;
           else W[n][a - 1] += v;
         }
@@ -591,6 +615,7 @@ __device__ TP_HELPER_ATTR void tp_solve_n(TpCtx c, TpRow Rin, double dinv, doubl
 }
 
 // res = M v with the distributed sparse rows (mj_mulM)
+template <bool CHAIN = false>
 __device__ TP_HELPER_ATTR double tp_mul_m(TpCtx c, TpRow Min, double v) {
   const double* Mr = Min.r;
   double res = c.dd > 0 ? Mr[0] * v : 0.0;
@@ -607,17 +632,18 @@ __device__ TP_HELPER_ATTR double tp_mul_m(TpCtx c, TpRow Min, double v) {
   for (int D = TP_MAXD; D >= 2; D--) {
     if (D > c.maxdd) continue;
     const bool is = c.dd == D, par = c.dd == D - 1;
+    const bool recv = par && c.dchild0 == c.self_sa + 4;  // CHAIN: the child dof is on the next lane
     double T[TP_MAXD];
 #pragma unroll
     for (int a = 1; a < TP_MAXD; a++)
       if (a < D) T[a] = is ? Mr[a] * v + W[a] : 0.0;
-    for (int ch = 0; ch < c.nchild[D]; ch++) {
+    for (int ch = 0; ch < (CHAIN && D >= 3 ? 1 : c.nchild[D]); ch++) {
       const int src = ch == 0 ? c.dchild0 : tp_child(c.tbl, TPL_DCHILD, ch);
       const int sa = par ? src : c.zero_sa;
 #pragma unroll
       for (int a = 1; a < TP_MAXD; a++) {
         if (a >= D) continue;
-        const double x = bperm(T[a], sa);
+        const double x = tp_up(T[a], sa, CHAIN && D >= 3, recv);
         if (a == 1) res += x;
         else W[a - 1] += x;
       }
@@ -1006,7 +1032,7 @@ __device__ __forceinline__ void tp_collide_prep(const DevModel& m, const TpModel
 // PGS: mj_solPGS (dual, projected Gauss-Seidel): M^-1 is formed column by
 // column in LDS, the sweep visits the rows in efc order, the owner lane of a row computes its new
 // force and broadcasts the change, every dof lane adds change * (M^-1 J^T)_i to its acceleration.
-template <bool CON, bool FULL, bool RK4, bool CG = false, bool PGS = false>
+template <bool CON, bool FULL, bool RK4, bool CG = false, bool PGS = false, bool CHAIN = false>
 __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, const DevData& d, int nsteps,
                                        int mode, int dump, TpShared sh, const ColModel& cm, const ColData& cd) {
   int* tbl = sh.tbl;
@@ -1296,12 +1322,12 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
         TpRow He = Mr;
         He.r[0] += h * damping;
         TpFac LE;
-        tp_factor2(c, Mr, He, LM, LE);
+        tp_factor2<CHAIN>(c, Mr, He, LM, LE);
 #pragma unroll
         for (int a = 0; a < TP_MAXD; a++) sh.park[a * 64 + tid] = LE.R.r[a];
         sh.park[TP_MAXD * 64 + tid] = LE.dinv;
       } else {
-        LM = tp_factor(c, Mr);
+        LM = tp_factor<CHAIN>(c, Mr);
       }
       TPC_T(15)
       TPC_T(16)
@@ -1326,8 +1352,8 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
       // M * qacc_warmstart (needed by the primal solvers' warm start) rides along in the solve's sweeps
       double Ma_ws = 0;
       const bool warm = !PGS && !(m.disableflags & BS_DSBL_WARMSTART) && !(m.disableflags & BS_DSBL_CONSTRAINT);
-      const double qacc_smooth = warm ? tp_solve_mulm(c, LM.R, LM.dinv, qfrc_smooth, Mr, qacc_ws, Ma_ws)
-                                      : tp_solve(c, LM.R, LM.dinv, qfrc_smooth);
+      const double qacc_smooth = warm ? tp_solve_mulm<CHAIN>(c, LM.R, LM.dinv, qfrc_smooth, Mr, qacc_ws, Ma_ws)
+                                      : tp_solve<CHAIN>(c, LM.R, LM.dinv, qfrc_smooth);
       const bool dump_now = stage == 0 && step == nsteps - 1 && env_ok && dump >= 1;
       if (dump_now) {
         // outputs of the step's mj_forward, stored as soon as they exist so they are not kept
@@ -1778,7 +1804,7 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
             if (left) left &= left - 1;
             x[n] = l == col[n] ? 1.0 : 0.0;
           }
-          tp_solve_n<3>(c, LM.R, LM.dinv, x);
+          tp_solve_n<3, CHAIN>(c, LM.R, LM.dinv, x);
 #pragma unroll
           for (int n = 0; n < 3; n++)
             if (col[n] >= 0 && l < m.nbody) Mrow[col[n]] = x[n];
@@ -1875,7 +1901,7 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
           }
           double jt = jtf();
           if constexpr (CON) { jt += con_jtf(cfo); if (!has_dof) jt = 0; }
-          const double w = tp_solve(c, LM.R, LM.dinv, jt);  // M^-1 J^T f
+          const double w = tp_solve<CHAIN>(c, LM.R, LM.dinv, jt);  // M^-1 J^T f
           const double wo = bperm(w, eq_other_sa), so = bperm(qacc_smooth, eq_other_sa);
           double cl = 0;
           if constexpr (CON) {
@@ -2011,7 +2037,7 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
           qfrc_constraint += con_jtf(cfo);
           if (!has_dof) qfrc_constraint = 0;
         }
-        qacc = qacc_smooth + tp_solve(c, LM.R, LM.dinv, qfrc_constraint);
+        qacc = qacc_smooth + tp_solve<CHAIN>(c, LM.R, LM.dinv, qfrc_constraint);
         if (!has_dof) qacc = 0;
         qacc_ws = qacc;
       } else {
@@ -2100,7 +2126,7 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
           if (iter >= m.iterations) break;
           TPC_T(5)
           if constexpr (CG) {
-            const double Mg = tp_solve(c, LM.R, LM.dinv, s.grad);  // every lane takes part in the sweeps
+            const double Mg = tp_solve<CHAIN>(c, LM.R, LM.dinv, s.grad);  // every lane takes part in the sweeps
             double beta = 0;
             if (iter > 0) {
               const double gg_old = env_sum(cg_grad * cg_Mgrad);
@@ -2134,12 +2160,12 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
 #endif
             s.search = has_dof ? -x : 0.0;
           } else {
-            const double x = tp_factor_solve(c, Hr, s.grad);
+            const double x = tp_factor_solve<CHAIN>(c, Hr, s.grad);
             s.search = has_dof ? -x : 0.0;
           }
           }
           TPC_T(9)
-          s.Mv = tp_mul_m(c, Mr, s.search);
+          s.Mv = tp_mul_m<CHAIN>(c, Mr, s.search);
           TPC_C(23)
           residual(s.search, 0.0, s.vf, s.vl0, s.vl1, s.ve, s.cv);
           TPC_C(24)
@@ -2218,13 +2244,13 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
 #pragma unroll
             for (int a = 0; a < TP_MAXD; a++) LE.R.r[a] = sh.park[a * 64 + tid];
             LE.dinv = sh.park[TP_MAXD * 64 + tid];
-            acc = tp_solve(c, LE.R, LE.dinv, rhs);
+            acc = tp_solve<CHAIN>(c, LE.R, LE.dinv, rhs);
           } else {
             // no early factor (k_tpc has no LDS to park it in): the forward substitution rides in the
             // factorisation's leaves-to-root exchanges, as in Newton's direction
             TpRow Hr = Mr;
             Hr.r[0] += h * damping;
-            acc = tp_factor_solve(c, Hr, rhs);
+            acc = tp_factor_solve<CHAIN>(c, Hr, rhs);
           }
         }
         qvel += h * acc;
