@@ -900,7 +900,7 @@ static void launch_tpc_pass(bs_sim* s, const DevData& dd, hipStream_t st, int mo
     return;
   }
   const size_t lds = (size_t)(2 * ntri + 2 * TP_LPE * TPC_SLOT + 2 * TP_LPE * 3) * sizeof(double);
-  auto* launch = s->dm.solver == 1 ? (full ? bs_launch_tpc_full_cg : bs_launch_tpc_cg) : (full ? bs_launch_tpc_full : bs_launch_tpc);
+  auto* launch = s->dm.solver == 1 ? (full ? bs_launch_tpc_full_cg : bs_launch_tpc_cg) : (full ? bs_launch_tpc_full : (s->tp.chain ? bs_launch_tpc_chain : bs_launch_tpc));
   launch(g, lds, st, s->dm, s->tp, dd, s->cm, s->cd, mode, dump);
 }
 // check: mj_checkPos/Vel first; integrate: mj_step (Euler) rather than mj_forward; fast: let the
@@ -1254,7 +1254,7 @@ extern "C" int bs_sim_kernel_path(const bs_sim* s, char* buf, int cap) {
     else if (s->contacts && s->cm.maxcon > TP_LPE) why = "more than 32 contacts per environment requested";
     else why = "not selected";
   }
-  snprintf(buf, (size_t)cap, "%s%s%s", tp ? (s->contacts ? "tree-parallel (k_tp_col, k_c_narrow_list, k_tpc)" : "tree-parallel (k_tp)")
+  snprintf(buf, (size_t)cap, "%s%s%s", tp ? (s->contacts ? "tree-parallel (k_tp_col, k_c_narrow_list, k_tpc)" : (s->tp.chain && s->dm.solver == 2 && s->dm.integrator == 0 ? "tree-parallel (k_tp_chain)" : "tree-parallel (k_tp)"))
                                              : (s->contacts ? "serial (k_c_pos, k_c_broad, k_c_narrow_flat, k_c_dyn): " : "serial (k_step): "),
            why.c_str(), "");
   return tp ? 1 : 0;

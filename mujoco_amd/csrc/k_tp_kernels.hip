@@ -23,14 +23,15 @@
 // contacts: candidates from k_tp_col + the narrowphase kernel, one step per launch.  Dynamic LDS:
 // packed Hessians for nbody rows (2 envs), then contact slots, then the U staging rows
 #define TPC_KERNEL(name, CG_, PGS_) TPC_KERNEL_F(name, false, CG_, PGS_)
-#define TPC_KERNEL_F(name, FULL_, CG_, PGS_)                                                                                   \
+#define TPC_KERNEL_F(name, FULL_, CG_, PGS_) TPC_KERNEL_FC(name, FULL_, CG_, PGS_, false)
+#define TPC_KERNEL_FC(name, FULL_, CG_, PGS_, CHAIN_)                                                                  \
   __global__ __launch_bounds__(64, TPC_OCC) void k_##name(DevModel m, TpModel t, DevData d, ColModel cm, ColData cd,  \
                                                           int mode, int dump) {                                      \
     __shared__ int tbl[TPL_TOTAL * 64];                                                                               \
     extern __shared__ double tpc_dyn[];                                                                               \
     const int ntri = m.nbody * (m.nbody + 1) / 2;                                                                     \
     const TpShared sh = {tbl, tpc_dyn, tpc_dyn + 2 * ntri, tpc_dyn + 2 * ntri + 2 * TP_LPE * TPC_SLOT, nullptr, nullptr}; \
-    tp_run<true, FULL_, false, CG_, PGS_>(m, t, d, 1, mode, dump, sh, cm, cd);                                        \
+    tp_run<true, FULL_, false, CG_, PGS_, CHAIN_>(m, t, d, 1, mode, dump, sh, cm, cd);                                \
   }                                                                                                                   \
   void bs_launch_##name(BS_TPC_ARGS) { hipLaunchKernelGGL(k_##name, g, dim3(64), lds, st, m, t, d, cm, cd, mode, dump); }
 
@@ -81,6 +82,8 @@ void bs_launch_tp_col(dim3 g, size_t lds, hipStream_t st, const DevModel& m, con
 #endif
 #elif defined(TPK_tpc)
 TPC_KERNEL(tpc, false, false)
+#elif defined(TPK_tpc_chain)
+TPC_KERNEL_FC(tpc_chain, false, false, false, true)  // Newton with contacts, chain models (see k_tp_chain)
 #elif defined(TPK_tpc_cg)
 TPC_KERNEL(tpc_cg, true, false)
 #elif defined(TPK_tpc_full)

@@ -68,6 +68,7 @@ void bs_launch_tp_col(dim3 g, size_t lds, hipStream_t st, const DevModel& m, con
                       const ColModel& cm, const ColData& cd);
 #define BS_TPC_ARGS dim3 g, size_t lds, hipStream_t st, const DevModel &m, const TpModel &t, const DevData &d, const ColModel &cm, const ColData &cd, int mode, int dump
 void bs_launch_tpc(BS_TPC_ARGS);        // contacts, Newton
+void bs_launch_tpc_chain(BS_TPC_ARGS);        // contacts, Newton
 void bs_launch_tpc_cg(BS_TPC_ARGS);     // contacts, CG
 void bs_launch_tpc_pgs(BS_TPC_ARGS);    // contacts, PGS
 void bs_launch_tpc_full(BS_TPC_ARGS);     // bs_forward with contacts, Newton: every intermediate written

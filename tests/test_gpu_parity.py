@@ -409,6 +409,32 @@ def test_two_stream_split_is_bitwise_neutral(hand_model, integrator, monkeypatch
             assert np.array_equal(a, b)
 
 
+def test_chain_kernel_is_bitwise_neutral(hand_model, monkeypatch):
+    """k_tp_chain (DPP shifts instead of ds_bpermute for the sweeps' packets on the single-child levels of
+    the dof tree; chosen when TpModel::chain holds, as for the hand) moves the same values between the same
+    lanes as k_tp: not a bit of the trajectory may differ.  BS_NO_CHAIN=1 selects the generic kernel."""
+    import torch
+    from mujoco_amd import BatchSim, workload
+    m = workload.contact_free(hand_model)
+    E = 130
+    q, v = workload.config2_state(m, E, seed=77)
+    c = workload.config2_ctrl(m, E, seed=77)
+    res = {}
+    for mode in ("chain", "generic"):
+        if mode == "generic":
+            monkeypatch.setenv("BS_NO_CHAIN", "1")
+        sim = BatchSim(m.copy(), n_envs=E)  # a fresh native model per mode: the flag is read when the model is built
+        assert ("k_tp_chain" in sim.kernel_path()[1]) == (mode == "chain")
+        sim.data.qpos.copy_(torch.as_tensor(q)); sim.data.qvel.copy_(torch.as_tensor(v)); sim.data.ctrl.copy_(torch.as_tensor(c))
+        sim.step(60); sim.sync()
+        res[mode] = [getattr(sim.data, k).cpu().numpy().copy() for k in ("qpos", "qvel", "qacc", "solver_iter", "xpos")]
+        del sim
+    monkeypatch.delenv("BS_NO_CHAIN")
+    assert np.abs(res["chain"][1]).max() > 1e-3
+    for a, b in zip(res["chain"], res["generic"]):
+        assert np.array_equal(a, b)
+
+
 def test_work_stealing_narrowphase(hand_model, monkeypatch):
     """BS_NARROW=ws (opt-in variant of the narrowphase) finds the same contacts as the default."""
     import torch
