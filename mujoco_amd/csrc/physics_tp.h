@@ -259,6 +259,7 @@ struct TpCtx {
   int dd;                // entries in this dof's row (0 = no dof on this lane)
   int maxdd;
   int nchild[TP_MAXD + 2];  // lvl_dchild
+  int top_sa;            // address of the lane's (dd - 1)-th ancestor dof: the one above its chain (CHAIN kernels)
   int dchild0;           // first entry of the lane's dof-child list (the LDS table's row 0): most levels have one child,
                          // so the sweeps' usual case needs no table read in front of the permutes
   tp_lds_ptr tbl;        // LDS table
@@ -395,10 +396,13 @@ __device__ TP_HELPER_ATTR double tp_factor_solve(TpCtx c, TpRow Rin, double x) {
   for (int D = 2; D <= TP_MAXD; D++) {
     if (D > c.maxdd) continue;
     const bool is = c.dd == D;
+    double xs = x;  // CHAIN: x of the lane a places below (the ancestors of a chain dof, up to the first branching)
 #pragma unroll
     for (int a = 1; a < TP_MAXD; a++) {
       if (a >= D) continue;
-      const double xa = bperm(x, c.anc_sa[a]);
+      double xa;
+      if (CHAIN && a <= D - 2) { xs = dpp_mov<0x138>(xs); xa = xs; }  // wave_shr:1
+      else xa = bperm(x, c.anc_sa[a]);
       if (is) x -= R[a] * xa;
     }
   }
@@ -498,10 +502,13 @@ __device__ TP_HELPER_ATTR double tp_solve(TpCtx c, TpRow Rin, double dinv, doubl
   for (int D = 2; D <= TP_MAXD; D++) {
     if (D > c.maxdd) continue;
     const bool is = c.dd == D;
+    double xs = x;  // CHAIN: x of the lane a places below (the ancestors of a chain dof, up to the first branching)
 #pragma unroll
     for (int a = 1; a < TP_MAXD; a++) {
       if (a >= D) continue;
-      const double xa = bperm(x, c.anc_sa[a]);
+      double xa;
+      if (CHAIN && a <= D - 2) { xs = dpp_mov<0x138>(xs); xa = xs; }  // wave_shr:1
+      else xa = bperm(x, c.anc_sa[a]);
       if (is) x -= R[a] * xa;
     }
   }
@@ -515,10 +522,18 @@ __device__ TP_HELPER_ATTR double tp_solve_mulm(TpCtx c, TpRow Rin, double dinv, 
   const double* R = Rin.r;
   const double* Mr = Min.r;
   double res = c.dd > 0 ? Mr[0] * v : 0.0;
+  double vs = v;
+  const double vtop = CHAIN ? bperm(v, c.top_sa) : 0.0;
 #pragma unroll
   for (int a = 1; a < TP_MAXD; a++) {
     if (a >= c.maxdd) continue;
-    const double va = bperm(v, c.anc_sa[a]);
+    double va;
+    if (CHAIN) {  // the a-th ancestor is the lane a places below, or (a == dd - 1) the dof above the chains
+      vs = dpp_mov<0x138>(vs);
+      va = a == c.dd - 1 ? vtop : vs;
+    } else {
+      va = bperm(v, c.anc_sa[a]);
+    }
     if (a < c.dd) res += Mr[a] * va;
   }
   double W[TP_MAXD], V[TP_MAXD];
@@ -551,10 +566,13 @@ __device__ TP_HELPER_ATTR double tp_solve_mulm(TpCtx c, TpRow Rin, double dinv, 
   for (int D = 2; D <= TP_MAXD; D++) {
     if (D > c.maxdd) continue;
     const bool is = c.dd == D;
+    double xs = x;  // CHAIN: x of the lane a places below (the ancestors of a chain dof, up to the first branching)
 #pragma unroll
     for (int a = 1; a < TP_MAXD; a++) {
       if (a >= D) continue;
-      const double xa = bperm(x, c.anc_sa[a]);
+      double xa;
+      if (CHAIN && a <= D - 2) { xs = dpp_mov<0x138>(xs); xa = xs; }  // wave_shr:1
+      else xa = bperm(x, c.anc_sa[a]);
       if (is) x -= R[a] * xa;
     }
   }
@@ -619,10 +637,18 @@ template <bool CHAIN = false>
 __device__ TP_HELPER_ATTR double tp_mul_m(TpCtx c, TpRow Min, double v) {
   const double* Mr = Min.r;
   double res = c.dd > 0 ? Mr[0] * v : 0.0;
+  double vs = v;
+  const double vtop = CHAIN ? bperm(v, c.top_sa) : 0.0;
 #pragma unroll
   for (int a = 1; a < TP_MAXD; a++) {
     if (a >= c.maxdd) continue;
-    const double va = bperm(v, c.anc_sa[a]);
+    double va;
+    if (CHAIN) {  // the a-th ancestor is the lane a places below, or (a == dd - 1) the dof above the chains
+      vs = dpp_mov<0x138>(vs);
+      va = a == c.dd - 1 ? vtop : vs;
+    } else {
+      va = bperm(v, c.anc_sa[a]);
+    }
     if (a < c.dd) res += Mr[a] * va;
   }
   double W[TP_MAXD];
@@ -1090,6 +1116,10 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
     const int v = lane_ref(TPI_ANC + a);
     c.anc_sa[a] = v >= 0 ? v : self_sa;
   }
+  c.top_sa = self_sa;
+#pragma unroll
+  for (int a = 1; a < TP_MAXD; a++)
+    if (a == c.dd - 1) c.top_sa = c.anc_sa[a];
 #pragma unroll
   for (int D = 0; D < TP_MAXD + 2; D++) c.nchild[D] = t.lvl_dchild[D];
 
@@ -1302,13 +1332,25 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
 #pragma unroll
         for (int k = 0; k < 6; k++) s0 += cdof[k] * buf[k];
         Mr.r[0] = has_dof ? lk[TPK_ARMATURE] + s0 : 1.0;
+        double cds[6], cdtop[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) { cds[k] = cdof[k]; cdtop[k] = CHAIN ? bperm(cdof[k], c.top_sa) : 0.0; }
 #pragma unroll
         for (int a = 1; a < TP_MAXD; a++) {
           Mr.r[a] = 0;
           if (a >= t.maxdd) continue;
           double sj = 0;
+          if constexpr (CHAIN) {
+            // the a-th ancestor's motion axis: a lanes below (shifted once more per a), or the top dof's (fetched once)
 #pragma unroll
-          for (int k = 0; k < 6; k++) sj += bperm(cdof[k], c.anc_sa[a]) * buf[k];
+            for (int k = 0; k < 6; k++) {
+              cds[k] = dpp_mov<0x138>(cds[k]);
+              sj += (a == c.dd - 1 ? cdtop[k] : cds[k]) * buf[k];
+            }
+          } else {
+#pragma unroll
+            for (int k = 0; k < 6; k++) sj += bperm(cdof[k], c.anc_sa[a]) * buf[k];
+          }
           if (a < c.dd) Mr.r[a] = sj;
         }
       }
