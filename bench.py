@@ -269,7 +269,8 @@ def contacts_block(model_path, E, local_rank, seed, steps, warmup, world, dist, 
                       "collective": ("RCCL all_gather obs[E,42]+reward fp32 per ctrl period, overlapped with the next steps"
                                      if gather_world else "none"),
                       "collision": cstat, **stats},
-           "roofline": roofline_block(m["launches"], E, flop, "k_tp_col + k_c_narrow_list + k_tpc (one step = 3 launches per range, "
+           "roofline": roofline_block(m["launches"], E, flop, "k_tp_col + k_c_narrow_list + "
+                                      + ("k_tpc_chain" if "k_tpc_chain" in w.sim.kernel_path()[1] else "k_tpc") + " (one step = 3 launches per range, "
                                       "3 ranges on 3 streams from 49 152 envs)", traffic, src,
                                       "flop model F = 36k + 12k N_np + 6k ncon n_iter with the measured N_np / ncon / n_iter of this run; "
                                       "duration = HIP events around every bs_step call of the timed regions; traffic = per step, all three kernels")}
@@ -438,11 +439,12 @@ def main():
 
     if rank == 0:
         wall = m["wall"]
-        kern = "k_tp" if args.solver == "newton" else ("k_tp_cg" if args.solver == "cg" else "k_tp_pgs")
+        chain = "k_tp_chain" in w.sim.kernel_path()[1] or "k_tpc_chain" in w.sim.kernel_path()[1]
+        kern = ("k_tp_chain" if chain else "k_tp") if args.solver == "newton" else ("k_tp_cg" if args.solver == "cg" else "k_tp_pgs")
         if args.contacts:
             traffic, src = pmc_traffic("contacts_pmc_per_step" if E == 65536 and not args.hull_verts else "none",
                                        ("k_tp_col", "k_c_narrow_list", "k_tpc"))
-            kern = "k_tp_col + k_c_narrow_list + " + {"newton": "k_tpc", "cg": "k_tpc_cg", "pgs": "k_tpc_pgs"}[args.solver]
+            kern = "k_tp_col + k_c_narrow_list + " + {"newton": "k_tpc_chain" if chain else "k_tpc", "cg": "k_tpc_cg", "pgs": "k_tpc_pgs"}[args.solver]
         else:
             traffic, src = pmc_traffic("config1_pmc_per_launch" if E == 4096 and args.solver == "newton" else "none", ("k_tp",))
         out = {

@@ -1254,7 +1254,7 @@ extern "C" int bs_sim_kernel_path(const bs_sim* s, char* buf, int cap) {
     else if (s->contacts && s->cm.maxcon > TP_LPE) why = "more than 32 contacts per environment requested";
     else why = "not selected";
   }
-  snprintf(buf, (size_t)cap, "%s%s%s", tp ? (s->contacts ? "tree-parallel (k_tp_col, k_c_narrow_list, k_tpc)" : (s->tp.chain && s->dm.solver == 2 && s->dm.integrator == 0 ? "tree-parallel (k_tp_chain)" : "tree-parallel (k_tp)"))
+  snprintf(buf, (size_t)cap, "%s%s%s", tp ? (s->contacts ? (s->tp.chain && s->dm.solver == 2 ? "tree-parallel (k_tp_col, k_c_narrow_list, k_tpc_chain)" : "tree-parallel (k_tp_col, k_c_narrow_list, k_tpc)") : (s->tp.chain && s->dm.solver == 2 && s->dm.integrator == 0 ? "tree-parallel (k_tp_chain)" : "tree-parallel (k_tp)"))
                                              : (s->contacts ? "serial (k_c_pos, k_c_broad, k_c_narrow_flat, k_c_dyn): " : "serial (k_step): "),
            why.c_str(), "");
   return tp ? 1 : 0;

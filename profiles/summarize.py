@@ -19,13 +19,19 @@ def agg(d):
         k = r["Kernel_Name"].split("(")[0]
         acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
         n[(k, r["Counter_Name"])] += 1
-    return {k.replace("void ", "").split("<")[0]: {a: b / n[(k, a)] for a, b in v.items()} for k, v in acc.items() if "k_" in k}
+    return {fam(k.replace("void ", "").split("<")[0]): {a: b / n[(k, a)] for a, b in v.items()} for k, v in acc.items() if "k_" in k}
+
+
+def fam(name):
+    """k_tp_chain / k_tpc_chain are the instantiations of k_tp / k_tpc this model runs (DPP shifts on the dof chains):
+    the summary keeps the family names its readers (bench.py) use; the kernel-stats CSVs keep the real ones."""
+    return name[:-6] if name.endswith("_chain") else name
 
 
 def stats(d, dst):
     f = glob.glob(f"gpurun_out/{d}/**/*kernel_stats.csv", recursive=True)[0]
     shutil.copy(f, dst)
-    return {r["Name"].split("(")[0].replace("void ", "").split("<")[0]: {"calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"])}
+    return {fam(r["Name"].split("(")[0].replace("void ", "").split("<")[0]): {"calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"])}
             for r in csv.DictReader(open(f)) if "k_" in r["Name"] and int(r["Calls"]) > 1}
 
 
@@ -42,7 +48,7 @@ for tag, ds in (("config1_pmc_per_launch", ["p_tp_fetch", "p_tp_write", "p_tp_sq
 # 21 800 envs at 65 536): per-step traffic = 3 x the per-launch averages
 out["contacts_pmc_per_step"] = {k: {a: 3 * b for a, b in v.items() if a in ("FETCH_SIZE", "WRITE_SIZE")}
                                 for k, v in out["contacts_pmc_per_launch"].items() if k in ("k_tp_col", "k_c_narrow_list", "k_tpc")}
-out["notes"] = ("per-launch averages over all dispatches of the kernel. config1 = `python3 bench.py --steps 500 --warmup 100 "
+out["notes"] = ("per-launch averages over all dispatches of the kernel; k_tp / k_tpc stand for the chain instantiations k_tp_chain / k_tpc_chain that this model runs. config1 = `python3 bench.py --steps 500 --warmup 100 "
                 "--no-cpu-baseline --no-extra-blocks` (k_tp: 50 steps x 4096 envs per launch); contacts = `python3 bench.py --contacts --envs 65536 "
                 "--steps 50 --warmup 50 --no-cpu-baseline` (one step per launch, three ranges of about 21 800 envs on three streams). "
                 "FETCH_SIZE / WRITE_SIZE in KB as rocprofv3 reports them; HBM-side traffic estimate = (2 x FETCH_SIZE + "
