@@ -20,6 +20,32 @@
   }                                                                                                                   \
   void bs_launch_##name(BS_TP_ARGS) { hipLaunchKernelGGL(k_##name, g, dim3(64), lds, st, m, t, d, nsteps, mode, dump); }
 
+// both instantiations in one kernel, chosen by TpModel::chain (uniform): for the variants that are not worth an
+// object file of their own per instantiation
+#define TP_KERNEL_D(name, CONTACTS_, FULL_, RK4_, CG_, PGS_, PARK_, MINV_)                                           \
+  __global__ __launch_bounds__(64, TP_OCC) void k_##name(DevModel m, TpModel t, DevData d, int nsteps, int mode, int dump) { \
+    __shared__ int tbl[TPL_TOTAL * 64];                                                                               \
+    __shared__ double park[PARK_ ? (TP_MAXD + 1) * 64 : 1];                                                           \
+    extern __shared__ double minv[];                                                                                  \
+    const TpShared sh = {tbl, nullptr, nullptr, nullptr, PARK_ ? park : nullptr, MINV_ ? minv : nullptr};             \
+    ColModel cm;                                                                                                      \
+    ColData cd;                                                                                                       \
+    if (t.chain) tp_run<CONTACTS_, FULL_, RK4_, CG_, PGS_, true>(m, t, d, nsteps, mode, dump, sh, cm, cd);            \
+    else tp_run<CONTACTS_, FULL_, RK4_, CG_, PGS_, false>(m, t, d, nsteps, mode, dump, sh, cm, cd);                   \
+  }                                                                                                                   \
+  void bs_launch_##name(BS_TP_ARGS) { hipLaunchKernelGGL(k_##name, g, dim3(64), lds, st, m, t, d, nsteps, mode, dump); }
+#define TPC_KERNEL_D(name, CG_, PGS_)                                                                                  \
+  __global__ __launch_bounds__(64, TPC_OCC) void k_##name(DevModel m, TpModel t, DevData d, ColModel cm, ColData cd,  \
+                                                          int mode, int dump) {                                      \
+    __shared__ int tbl[TPL_TOTAL * 64];                                                                               \
+    extern __shared__ double tpc_dyn[];                                                                               \
+    const int ntri = m.nbody * (m.nbody + 1) / 2;                                                                     \
+    const TpShared sh = {tbl, tpc_dyn, tpc_dyn + 2 * ntri, tpc_dyn + 2 * ntri + 2 * TP_LPE * TPC_SLOT, nullptr, nullptr}; \
+    if (t.chain) tp_run<true, false, false, CG_, PGS_, true>(m, t, d, 1, mode, dump, sh, cm, cd);                     \
+    else tp_run<true, false, false, CG_, PGS_, false>(m, t, d, 1, mode, dump, sh, cm, cd);                            \
+  }                                                                                                                   \
+  void bs_launch_##name(BS_TPC_ARGS) { hipLaunchKernelGGL(k_##name, g, dim3(64), lds, st, m, t, d, cm, cd, mode, dump); }
+
 // contacts: candidates from k_tp_col + the narrowphase kernel, one step per launch.  Dynamic LDS:
 // packed Hessians for nbody rows (2 envs), then contact slots, then the U staging rows
 #define TPC_KERNEL(name, CG_, PGS_) TPC_KERNEL_F(name, false, CG_, PGS_)
@@ -42,15 +68,15 @@ TP_KERNEL(tp, false, false, false, false, false, true, false)
 // consecutive lanes (TpModel::chain): the sweeps' packets of those levels move by DPP shifts
 TP_KERNEL_C(tp_chain, false, false, false, false, false, true, false, true)
 #elif defined(TPK_tp_cg)
-TP_KERNEL(tp_cg, false, false, false, true, false, true, false)
+TP_KERNEL_D(tp_cg, false, false, false, true, false, true, false)
 #elif defined(TPK_tp_pgs)
-TP_KERNEL(tp_pgs, false, false, false, false, true, false, true)
+TP_KERNEL_D(tp_pgs, false, false, false, false, true, false, true)
 #elif defined(TPK_tp_rk4)
-TP_KERNEL(tp_rk4, false, false, true, false, false, false, false)
+TP_KERNEL_D(tp_rk4, false, false, true, false, false, false, false)
 #elif defined(TPK_tp_rk4_cg)
-TP_KERNEL(tp_rk4_cg, false, false, true, true, false, false, false)
+TP_KERNEL_D(tp_rk4_cg, false, false, true, true, false, false, false)
 #elif defined(TPK_tp_rk4_pgs)
-TP_KERNEL(tp_rk4_pgs, false, false, true, false, true, false, true)
+TP_KERNEL_D(tp_rk4_pgs, false, false, true, false, true, false, true)
 #elif defined(TPK_tp_full)
 TP_KERNEL(tp_full, false, true, false, false, false, false, false)
 #elif defined(TPK_tp_full_cg)
@@ -85,7 +111,7 @@ TPC_KERNEL(tpc, false, false)
 #elif defined(TPK_tpc_chain)
 TPC_KERNEL_FC(tpc_chain, false, false, false, true)  // Newton with contacts, chain models (see k_tp_chain)
 #elif defined(TPK_tpc_cg)
-TPC_KERNEL(tpc_cg, true, false)
+TPC_KERNEL_D(tpc_cg, true, false)
 #elif defined(TPK_tpc_full)
 // bs_forward with contacts: every intermediate written (the FULL dump of k_tp_full + the contact list)
 TPC_KERNEL_F(tpc_full, true, false, false)
