@@ -315,7 +315,7 @@ __device__ TP_HELPER_ATTR TpFac tp_factor(TpCtx c, TpRow Rin) {
     if (D == 1) break;
     const bool par = c.dd == D - 1;
     const bool recv = par && c.dchild0 == c.self_sa + 4;  // CHAIN: the child dof is on the next lane
-    for (int ch = 0; ch < (CHAIN && D >= 3 ? 1 : c.nchild[D]); ch++) {
+    auto round = [&](int ch) {
       const int src = ch == 0 ? c.dchild0 : tp_child(c.tbl, TPL_DCHILD, ch);
       const int sa = par ? src : c.zero_sa;
 #pragma unroll
@@ -329,6 +329,13 @@ __device__ TP_HELPER_ATTR TpFac tp_factor(TpCtx c, TpRow Rin) {
           else A[pair_idx(a - 1, b - 1)] += v;
         }
       }
+    };
+    if (CHAIN && D == 2) {  // the branching level: every child's fetch issued before the first accumulation (table
+                            // entries beyond the children name the zero lane), same order of accumulation
+#pragma unroll
+      for (int ch = 0; ch < TP_MAXC; ch++) round(ch);
+    } else {
+      for (int ch = 0; ch < (CHAIN && D >= 3 ? 1 : c.nchild[D]); ch++) round(ch);
     }
   }
   TpFac out;
@@ -372,7 +379,7 @@ __device__ TP_HELPER_ATTR double tp_factor_solve(TpCtx c, TpRow Rin, double x) {
     if (D == 1) break;
     const bool par = c.dd == D - 1;
     const bool recv = par && c.dchild0 == c.self_sa + 4;  // CHAIN: the child dof is on the next lane
-    for (int ch = 0; ch < (CHAIN && D >= 3 ? 1 : c.nchild[D]); ch++) {
+    auto round = [&](int ch) {
       const int src = ch == 0 ? c.dchild0 : tp_child(c.tbl, TPL_DCHILD, ch);
       const int sa = par ? src : c.zero_sa;
 #pragma unroll
@@ -389,6 +396,13 @@ __device__ TP_HELPER_ATTR double tp_factor_solve(TpCtx c, TpRow Rin, double x) {
           else A[pair_idx(a - 1, b - 1)] += v;
         }
       }
+    };
+    if (CHAIN && D == 2) {  // the branching level: every child's fetch issued before the first accumulation (table
+                            // entries beyond the children name the zero lane), same order of accumulation
+#pragma unroll
+      for (int ch = 0; ch < TP_MAXC; ch++) round(ch);
+    } else {
+      for (int ch = 0; ch < (CHAIN && D >= 3 ? 1 : c.nchild[D]); ch++) round(ch);
     }
   }
   x *= dinv;
@@ -445,7 +459,7 @@ __device__ TP_HELPER_ATTR void tp_factor2(TpCtx c, TpRow R0in, TpRow R1in, TpFac
     if (D == 1) break;
     const bool par = c.dd == D - 1;
     const bool recv = par && c.dchild0 == c.self_sa + 4;  // CHAIN: the child dof is on the next lane
-    for (int ch = 0; ch < (CHAIN && D >= 3 ? 1 : c.nchild[D]); ch++) {
+    auto round = [&](int ch) {
       const int src = ch == 0 ? c.dchild0 : tp_child(c.tbl, TPL_DCHILD, ch);
       const int sa = par ? src : c.zero_sa;
 #pragma unroll
@@ -462,6 +476,13 @@ __device__ TP_HELPER_ATTR void tp_factor2(TpCtx c, TpRow R0in, TpRow R1in, TpFac
           }
         }
       }
+    };
+    if (CHAIN && D == 2) {  // the branching level: every child's fetch issued before the first accumulation (table
+                            // entries beyond the children name the zero lane), same order of accumulation
+#pragma unroll
+      for (int ch = 0; ch < TP_MAXC; ch++) round(ch);
+    } else {
+      for (int ch = 0; ch < (CHAIN && D >= 3 ? 1 : c.nchild[D]); ch++) round(ch);
     }
   }
 #pragma unroll
@@ -485,7 +506,7 @@ __device__ TP_HELPER_ATTR double tp_solve(TpCtx c, TpRow Rin, double dinv, doubl
 #pragma unroll
     for (int a = 1; a < TP_MAXD; a++)
       if (a < D) T[a] = is ? R[a] * x + W[a] : 0.0;
-    for (int ch = 0; ch < (CHAIN && D >= 3 ? 1 : c.nchild[D]); ch++) {
+    auto round = [&](int ch) {
       const int src = ch == 0 ? c.dchild0 : tp_child(c.tbl, TPL_DCHILD, ch);
       const int sa = par ? src : c.zero_sa;
 #pragma unroll
@@ -495,6 +516,13 @@ __device__ TP_HELPER_ATTR double tp_solve(TpCtx c, TpRow Rin, double dinv, doubl
         if (a == 1) x -= v;
         else W[a - 1] += v;
       }
+    };
+    if (CHAIN && D == 2) {  // the branching level: every child's fetch issued before the first accumulation (table
+                            // entries beyond the children name the zero lane), same order of accumulation
+#pragma unroll
+      for (int ch = 0; ch < TP_MAXC; ch++) round(ch);
+    } else {
+      for (int ch = 0; ch < (CHAIN && D >= 3 ? 1 : c.nchild[D]); ch++) round(ch);
     }
   }
   x *= dinv;
@@ -548,7 +576,7 @@ __device__ TP_HELPER_ATTR double tp_solve_mulm(TpCtx c, TpRow Rin, double dinv, 
 #pragma unroll
     for (int a = 1; a < TP_MAXD; a++)
       if (a < D) { T[a] = is ? R[a] * x + W[a] : 0.0; U[a] = is ? Mr[a] * v + V[a] : 0.0; }
-    for (int ch = 0; ch < (CHAIN && D >= 3 ? 1 : c.nchild[D]); ch++) {
+    auto round = [&](int ch) {
       const int src = ch == 0 ? c.dchild0 : tp_child(c.tbl, TPL_DCHILD, ch);
       const int sa = par ? src : c.zero_sa;
 #pragma unroll
@@ -558,6 +586,13 @@ __device__ TP_HELPER_ATTR double tp_solve_mulm(TpCtx c, TpRow Rin, double dinv, 
         if (a == 1) { x -= t; res += u; }
         else { W[a - 1] += t; V[a - 1] += u; }
       }
+    };
+    if (CHAIN && D == 2) {  // the branching level: every child's fetch issued before the first accumulation (table
+                            // entries beyond the children name the zero lane), same order of accumulation
+#pragma unroll
+      for (int ch = 0; ch < TP_MAXC; ch++) round(ch);
+    } else {
+      for (int ch = 0; ch < (CHAIN && D >= 3 ? 1 : c.nchild[D]); ch++) round(ch);
     }
   }
   mv = res;
@@ -599,7 +634,7 @@ __device__ TP_HELPER_ATTR void tp_solve_n(TpCtx c, TpRow Rin, double dinv, doubl
 #pragma unroll
       for (int a = 1; a < TP_MAXD; a++)
         if (a < D) T[n][a] = is ? R[a] * x[n] + W[n][a] : 0.0;
-    for (int ch = 0; ch < (CHAIN && D >= 3 ? 1 : c.nchild[D]); ch++) {
+    auto round = [&](int ch) {
       const int src = ch == 0 ? c.dchild0 : tp_child(c.tbl, TPL_DCHILD, ch);
       const int sa = par ? src : c.zero_sa;
 #pragma unroll
@@ -612,6 +647,13 @@ __device__ TP_HELPER_ATTR void tp_solve_n(TpCtx c, TpRow Rin, double dinv, doubl
           else W[n][a - 1] += v;
         }
       }
+    };
+    if (CHAIN && D == 2) {  // the branching level: every child's fetch issued before the first accumulation (table
+                            // entries beyond the children name the zero lane), same order of accumulation
+#pragma unroll
+      for (int ch = 0; ch < TP_MAXC; ch++) round(ch);
+    } else {
+      for (int ch = 0; ch < (CHAIN && D >= 3 ? 1 : c.nchild[D]); ch++) round(ch);
     }
   }
 #pragma unroll
@@ -663,7 +705,7 @@ __device__ TP_HELPER_ATTR double tp_mul_m(TpCtx c, TpRow Min, double v) {
 #pragma unroll
     for (int a = 1; a < TP_MAXD; a++)
       if (a < D) T[a] = is ? Mr[a] * v + W[a] : 0.0;
-    for (int ch = 0; ch < (CHAIN && D >= 3 ? 1 : c.nchild[D]); ch++) {
+    auto round = [&](int ch) {
       const int src = ch == 0 ? c.dchild0 : tp_child(c.tbl, TPL_DCHILD, ch);
       const int sa = par ? src : c.zero_sa;
 #pragma unroll
@@ -673,6 +715,13 @@ __device__ TP_HELPER_ATTR double tp_mul_m(TpCtx c, TpRow Min, double v) {
         if (a == 1) res += x;
         else W[a - 1] += x;
       }
+    };
+    if (CHAIN && D == 2) {  // the branching level: every child's fetch issued before the first accumulation (table
+                            // entries beyond the children name the zero lane), same order of accumulation
+#pragma unroll
+      for (int ch = 0; ch < TP_MAXC; ch++) round(ch);
+    } else {
+      for (int ch = 0; ch < (CHAIN && D >= 3 ? 1 : c.nchild[D]); ch++) round(ch);
     }
   }
   return res;
