@@ -982,6 +982,7 @@ static void launch_step(bs_sim* s, int n_steps) {
   }
 }
 
+static thread_local int tl_part_of_mixed = 0;  // bs_sim_create is creating a part of a mixed-model sim
 extern "C" int bs_sim_create(const bs_model* const* models, int n_models, const int32_t* env_model_id,
                              int64_t n_envs, int device, const bs_options* opt, bs_sim** out) {
   (void)opt;
@@ -1006,7 +1007,9 @@ extern "C" int bs_sim_create(const bs_model* const* models, int n_models, const 
       while (i < n_envs && env_model_id[i] == k) i++;
       if (i == start) continue;  // no environment uses this model
       bs_sim* child = nullptr;
+      tl_part_of_mixed = 1;  // the parts already step concurrently on three streams: a part keeps the old split threshold
       const int rc = bs_sim_create(models + k, 1, nullptr, i - start, device, opt, &child);
+      tl_part_of_mixed = 0;
       if (rc) { bs_sim_destroy(top); return rc; }
       top->parts.push_back(child);
       top->part_start.push_back(start);
@@ -1220,7 +1223,7 @@ extern "C" int bs_sim_create(const bs_model* const* models, int n_models, const 
     // ranges of a contact batch run on separate streams; every range is a whole number of 64-env
     // blocks and non-empty (the count is lowered until that holds)
     const char* sp = getenv("BS_SPLIT");
-    int np = sp ? atoi(sp) : (n_envs >= 8192 ? 3 : 1);  // measured: 3 ranges win from 8192 envs (14.6 vs 12.7 M env-steps/s; 27.5 vs 26.9 M at 65 536), 4 lose
+    int np = sp ? atoi(sp) : (n_envs >= (tl_part_of_mixed ? 8192 : 1024) ? 3 : 1);  // measured at the end of round 2: 3 ranges win from 1024 envs (4.12 vs 3.95 M env-steps/s; 14.0 vs 13.0 M at 4096; 24.6 vs 19.2 M at 8192; 34.2 vs 33.7 M for 2 ranges at 65 536), 4 lose
     np = np < 1 ? 1 : (np > 4 ? 4 : np);
     if (!s->use_tpc) np = 1;
     while (np > 1 && (n_envs < 128L * np || split_chunk(n_envs, np) * (np - 1) >= n_envs)) np--;
