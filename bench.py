@@ -271,7 +271,7 @@ def contacts_block(model_path, E, local_rank, seed, steps, warmup, world, dist, 
                       "collision": cstat, **stats},
            "roofline": roofline_block(m["launches"], E, flop, "k_tp_col + k_c_narrow_list + "
                                       + ("k_tpc_chain" if "k_tpc_chain" in w.sim.kernel_path()[1] else "k_tpc") + " (one step = 3 launches per range, "
-                                      "3 ranges on 3 streams from 49 152 envs)", traffic, src,
+                                      "3 ranges on 3 streams)", traffic, src,
                                       "flop model F = 36k + 12k N_np + 6k ncon n_iter with the measured N_np / ncon / n_iter of this run; "
                                       "duration = HIP events around every bs_step call of the timed regions; traffic = per step, all three kernels")}
     if with_cpu:
