@@ -1,24 +1,25 @@
 #!/usr/bin/env python3
 """bench.py — env-steps/s of the batched physics step (BASELINE.json metric).
 
-`python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on rank 0.
+`python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on rank 0.  From a plain shell (no
+WORLD_SIZE in the environment) `--gpus N > 1` starts its own ranks: `python -m torch.distributed.run
+--nproc-per-node N bench.py ...` as a child process (mujoco_amd/launch.py), before anything here touches the GPU;
+the child's JSON line is relayed and its exit code returned.
 
-N = 1 (default):  headline = BASELINE.json configs[1] — DexterousDynamos.xml joint-space only (contacts
-  disabled), 4096 lockstep envs, random ctrl resampled every 50 steps, Euler + Newton, fp64 — with its
-  `roofline` (k_tp) and `cpu_baseline`; next to it the blocks
-    "contacts_65536":   configs[2] — STL-hull self-collision + ground plane, 65 536 envs (the north-star
-                        workload: value, ms_per_step, collision work model, histograms, roofline, cpu_baseline)
-    "contacts_131072":  configs[4]'s per-GPU share — the same with 131 072 envs and the per-control-period
-                        RCCL all-gather of obs/reward (one rank): the N = 1 point of the N > 1 curve below.
-N > 1 (launched by torch.distributed.run, one rank per GPU): configs[4]'s shape — every rank steps its own
-  131 072 envs with contacts (weak scaling, no traffic inside a step) and all-gathers obs (qpos|qvel fp32) +
-  reward once per control period (50 steps) over RCCL, overlapped with the next steps.  `value` is the
-  whole-job rate; compare it with N x the N = 1 run's contacts_131072.value.
+Headline at EVERY N — BASELINE.json configs[4]'s shape, one workload per GPU so that the 1 -> 8 curve divides
+like by like: DexterousDynamos.xml with STL-hull mesh self-collision + a ground plane (the plane is this build's
+augmentation), 131 072 envs per GPU, Euler + Newton, fp64, ctrl resampled every 50 steps, obs (qpos|qvel fp32) +
+reward all-gathered over RCCL once per control period, overlapped with the next steps (weak scaling, no traffic
+inside a step).  The line carries `ranks_joined` (an all-reduce of 1) and every rank's device name.
+N = 1 adds, in the same line, `cpu_baseline` (the oracle on the same workload) and the blocks
+    "config1_4096":    configs[1] — joint-space only (contacts disabled), 4096 lockstep envs (k_tp_chain), with its
+                       own `roofline` and `cpu_baseline`;
+    "contacts_65536":  configs[2] — the headline's model at 65 536 envs without the collective, with `roofline`.
 
-A "step" is one mj_step of the whole batch.  State and the ctrl bank are resident in HBM before the
-timed region.  Timing: W warm-up steps, then the K-step region is timed R = 5 times back to back (each
-bracketed by barrier + synchronize, MAX over ranks) and the MEDIAN is reported with `steps` = K, so a
-short K (the driver's 20) does not measure one launch's jitter.
+A "step" is one mj_step of the whole batch.  State and the ctrl bank are resident in HBM before the timed
+region.  Timing: W warm-up steps, then the K-step region is timed R >= 5 times back to back (each bracketed by
+barrier + synchronize, MAX over ranks) and the MEDIAN is reported with `steps` = K, so a short K (the driver's
+20) does not measure one launch's jitter.
 """
 import argparse
 import json
@@ -37,18 +38,34 @@ FP64_PEAK_TFLOPS = 78.6         # MI355X fp64 vector == fp64 matrix peak (datash
 CTRL_PERIOD = 50
 REPS = 15                       # repetitions of the timed K-step region (median reported); 5 once they have taken REPS_BUDGET_S
 REPS_BUDGET_S = 8.0
+PMC_FILES = ("r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json")
+FLOP_PER_MPR_ITER = 1.01e3      # 2 hill-climb supports x ~430 + 150 simplex update (12 k per pair = 12 of these)
 
 
 def pmc_traffic(section, kernels):
     """HBM-side bytes per launch of `kernels` (summed) from the committed rocprofv3 PMC summary of this
     round if present, else of round 1: (2 x FETCH_SIZE + WRITE_SIZE) KB, the gfx950 correction of
     MI355X_MICROARCH.md.  bench.py cannot collect counters itself; None if the summary is missing."""
-    for name in ("r02_pmc_summary.json", "r01_pmc_summary.json"):
+    for name in PMC_FILES:
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 sec = json.load(f)[section]
             return sum((2.0 * sec[k]["FETCH_SIZE"] + sec[k]["WRITE_SIZE"]) * 1024.0 for k in kernels), name
         except (OSError, KeyError, ValueError):
+            continue
+    return None, None
+
+
+def pmc_hw_flop(workload):
+    """fp64 flop the hardware ISSUED per env-step (SQ_INSTS_VALU_{FMA x 2, ADD, MUL, TRANS}_F64 x 64 lanes, all
+    kernels of the step) from the committed PMC summary: (flop per env-step, file) or (None, None).  Counted per
+    wavefront instruction, so lanes that are masked off count as issued: an upper bound of the useful work and
+    the figure to hold against the 78.6 TFLOP/s the vector ALU can issue."""
+    for name in PMC_FILES:
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                return float(json.load(f)["hw_fp64_flop_per_env_step"][workload]), name
+        except (OSError, KeyError, ValueError, TypeError):
             continue
     return None, None
 
@@ -165,9 +182,9 @@ class Workload:
             self.period += 1
 
     def close(self):
-        """Destroy the sim NOW (BatchSim <-> BatchData is a reference cycle, so `del` alone leaves its streams
-        alive until the cyclic collector runs: with GPU_MAX_HW_QUEUES = 4 the three streams of the next contact
-        sim would then share hardware queues and its ranges would not overlap: measured 2.86 instead of 2.38 ms/step)."""
+        """Destroy the sim NOW rather than when the last Python reference goes: with GPU_MAX_HW_QUEUES = 4 the three
+        streams of a contact sim that is still alive share hardware queues with the next one's, whose ranges then do
+        not overlap (measured 2.86 instead of 2.38 ms/step when `sim.data` still held its sim strongly)."""
         self.gather = None
         self.launch_events = []
         self.sim.close()
@@ -223,7 +240,8 @@ class Workload:
         return out
 
     def collision_model(self, iters):
-        """Measured work model of SURVEY.md §8(d): N_np, MPR iterations, ncon per env-step over one control period."""
+        """Measured work model of SURVEY.md §8(d): N_np, MPR iterations, ncon per env-step over one control period.
+        -> (stats, flop per env-step by the contract's formula, the same with the MEASURED MPR iteration count)."""
         sim = self.sim
         sim.collision_stats(reset=True)
         sim.step(CTRL_PERIOD)
@@ -232,28 +250,50 @@ class Workload:
         c = {"narrow_pairs_per_env_step": st["narrow_pairs"] / n,
              "mpr_iter_per_pair": st["mpr_iterations"] / max(1, st["narrow_pairs"]),
              "ncon_per_env_step": st["contacts"] / n}
-        # F = 36k + 12k N_np + 6k ncon n_iter
-        flop = FLOP_PER_ENV_STEP + 12e3 * c["narrow_pairs_per_env_step"] + 6e3 * c["ncon_per_env_step"] * max(iters, 1.0)
-        return c, flop
+        # contract: F = 36k + 12k N_np + 6k ncon n_iter (12 k per pair = 12 portal iterations of 1.01 k);
+        # measured: the pair term with this run's own iteration count
+        solver = 6e3 * c["ncon_per_env_step"] * max(iters, 1.0)
+        flop = FLOP_PER_ENV_STEP + 12e3 * c["narrow_pairs_per_env_step"] + solver
+        flop_meas = FLOP_PER_ENV_STEP + FLOP_PER_MPR_ITER * c["mpr_iter_per_pair"] * c["narrow_pairs_per_env_step"] + solver
+        return c, flop, flop_meas
 
 
-def roofline_block(launches, E, flop_env_step, kernel, traffic, traffic_src, note):
+def roofline_block(launches, E, flop_env_step, kernel, traffic, traffic_src, note, flop_measured=None, hw=(None, None)):
     """achieved = algorithmic flop of the event-timed launches / their summed duration."""
     ms = sum(t for t, _ in launches)
     steps = sum(n for _, n in launches)
-    achieved = flop_env_step * E * steps / (ms * 1e-3) / 1e12
+    rate = E * steps / (ms * 1e-3)  # env-steps/s inside the event-timed bs_step calls
+    achieved = flop_env_step * rate / 1e12
     per_launch_steps = max(n for _, n in launches)
     full = [t for t, n in launches if n == per_launch_steps]
-    return {"bound": "mfma", "bound_detail": "fp64 vector ALU (no MFMA instruction is used; the contract's two labels are hbm|mfma "
-                                             "and this is the compute one)",
-            "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS,
-            "traffic": traffic, "traffic_source": traffic_src, "kernel": kernel,
-            "launch_ms": float(np.mean(full)), "steps_per_launch": per_launch_steps, "launches_timed": len(launches),
-            "env_steps_per_launch": E * per_launch_steps, "flop_per_env_step": flop_env_step,
-            "algorithmic_hbm_GBps": BYTES_PER_ENV_STEP * E * steps / (ms * 1e-3) / 1e9, "note": note}
+    out = {"bound": "mfma", "bound_actual": "fp64_valu_latency",
+           "bound_detail": "fp64 vector ALU, latency-bound (dependent fp64 / cross-lane chains; no MFMA instruction is used; the "
+                           "contract's two labels are hbm|mfma and this is the compute one)",
+           "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS,
+           "traffic": traffic, "traffic_source": traffic_src, "kernel": kernel,
+           "launch_ms": float(np.mean(full)), "steps_per_launch": per_launch_steps, "launches_timed": len(launches),
+           "env_steps_per_launch": E * per_launch_steps, "flop_per_env_step": flop_env_step,
+           "algorithmic_hbm_GBps": BYTES_PER_ENV_STEP * rate / 1e9, "note": note}
+    if flop_measured is not None:
+        out["flop_per_env_step_measured"] = flop_measured
+        out["achieved_measured"] = flop_measured * rate / 1e12
+        out["frac_measured"] = out["achieved_measured"] / FP64_PEAK_TFLOPS
+        out["measured_note"] = ("the contract formula prices a narrowphase pair at 12 portal iterations; *_measured uses this run's "
+                                "mpr_iter_per_pair x 1.01 kflop instead — the honest figure when the two differ")
+    if hw[0] is not None:
+        out["hw_fp64_flop_per_env_step"] = hw[0]
+        out["hw_fp64_tflops"] = hw[0] * rate / 1e12
+        out["hw_fp64_frac"] = out["hw_fp64_tflops"] / FP64_PEAK_TFLOPS
+        out["hw_fp64_source"] = (f"profiles/{hw[1]}: SQ_INSTS_VALU_(2 x FMA + ADD + MUL + TRANS)_F64 x 64 lanes per env-step of the "
+                                 "profiled run (masked lanes count as issued), times this run's env-steps/s")
+    return out
 
 
-def contacts_block(model_path, E, local_rank, seed, steps, warmup, world, dist, gather_world, with_cpu, label):
+CONTACT_LABEL = ("DexterousDynamos.xml with STL-hull mesh self-collision + a ground plane at z=-0.05 (the plane is this build's "
+                 "augmentation, not in the reference XML), Euler + Newton, fp64, ctrl resampled every 50 steps")
+
+
+def contacts_block(model_path, E, local_rank, seed, steps, warmup, world, dist, gather_world, label):
     """configs[2] / configs[4]-share: contacts + ground plane at E envs per GPU."""
     import torch
     from mujoco_amd import Model, workload
@@ -261,24 +301,54 @@ def contacts_block(model_path, E, local_rank, seed, steps, warmup, world, dist, 
     w = Workload(model, E, local_rank, seed, gather_world=gather_world, dist=dist)
     m = w.measure(steps, warmup)
     stats = w.state_stats()
-    cstat, flop = w.collision_model(stats["mean_solver_iter"])
+    cstat, flop, flop_meas = w.collision_model(stats["mean_solver_iter"])
     traffic, src = pmc_traffic("contacts_pmc_per_step" if E == 65536 else "none", ("k_tp_col", "k_c_narrow_list", "k_tpc"))
+    path = w.sim.kernel_path()[1]
     blk = {"value": E * world * steps / m["wall"], "unit": "env-steps/s", "ms_per_step": m["wall"] * 1e3 / steps,
            "steps": steps, "reps": len(m["walls"]), "wall_s_all_reps": m["walls"],
            "config": {"workload": label, "n_envs_per_gpu": E, "n_envs_total": E * world, "ctrl_period": CTRL_PERIOD,
                       "collective": ("RCCL all_gather obs[E,42]+reward fp32 per ctrl period, overlapped with the next steps"
                                      if gather_world else "none"),
-                      "collision": cstat, **stats},
+                      "kernel_path": path, "collision": cstat, **stats},
            "roofline": roofline_block(m["launches"], E, flop, "k_tp_col + k_c_narrow_list + "
-                                      + ("k_tpc_chain" if "k_tpc_chain" in w.sim.kernel_path()[1] else "k_tpc") + " (one step = 3 launches per range, "
+                                      + ("k_tpc_chain" if "k_tpc_chain" in path else "k_tpc") + " (one step = 3 launches per range, "
                                       "3 ranges on 3 streams)", traffic, src,
                                       "flop model F = 36k + 12k N_np + 6k ncon n_iter with the measured N_np / ncon / n_iter of this run; "
-                                      "duration = HIP events around every bs_step call of the timed regions; traffic = per step, all three kernels")}
+                                      "duration = HIP events around every bs_step call of the timed regions; traffic = per step, all three kernels",
+                                      flop_measured=flop_meas, hw=pmc_hw_flop("contacts"))}
+    w.close()
+    del w
+    torch.cuda.empty_cache()
+    return blk, model
+
+
+def config1_block(model_path, E, local_rank, seed, steps, warmup, with_cpu):
+    """configs[1]: joint-space only (contacts disabled), E lockstep envs on one GPU."""
+    import torch
+    from mujoco_amd import Model, workload
+    model = workload.contact_free(Model.load(model_path))
+    w = Workload(model, E, local_rank, seed)
+    m = w.measure(steps, warmup)
+    stats = w.state_stats()
+    path = w.sim.kernel_path()[1]
+    kern = "k_tp_chain" if "k_tp_chain" in path else "k_tp"
+    traffic, src = pmc_traffic("config1_pmc_per_launch" if E == 4096 else "none", ("k_tp",))
+    blk = {"value": E * steps / m["wall"], "unit": "env-steps/s", "ms_per_step": m["wall"] * 1e3 / steps,
+           "steps": steps, "reps": len(m["walls"]), "wall_s_all_reps": m["walls"],
+           "config": {"workload": "BASELINE.json configs[1]: DexterousDynamos.xml joint-space only (contacts disabled), lockstep "
+                                  "envs, random ctrl resampled every 50 steps, Euler + Newton, fp64",
+                      "n_envs_per_gpu": E, "n_envs_total": E, "ctrl_period": CTRL_PERIOD, "collective": "none",
+                      "kernel_path": path, **stats},
+           "roofline": roofline_block(m["launches"], E, FLOP_PER_ENV_STEP, kern, traffic, src,
+                                      "duration = HIP events on the kernels' stream around every bs_step call of the timed regions "
+                                      "(one call = one launch of min(50, steps) steps); traffic = bytes per 50-step launch from the "
+                                      "committed PMC summary (prologue / epilogue state + outputs + spill scratch, not per-step traffic)",
+                                      hw=pmc_hw_flop("config1"))}
     if with_cpu:
-        blk["cpu_baseline"] = cpu_baseline(model, seconds_budget=10.0, n_steps=200)
+        blk["cpu_baseline"] = cpu_baseline(model, n_steps=1000)
         try:
-            blk["cpu_baseline_allcores"] = cpu_baseline_allcores(model_path, True)
-        except Exception as ex:
+            blk["cpu_baseline_allcores"] = cpu_baseline_allcores(model_path, False)
+        except Exception as ex:  # the pool is informational; the single-thread figure is the contract
             blk["cpu_baseline_allcores"] = {"error": repr(ex)}
     w.close()
     del w
@@ -354,12 +424,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--envs", type=int, default=0, help="environments per GPU (default: 4096 at N = 1, 131072 at N > 1)")
+    ap.add_argument("--envs", type=int, default=0, help="environments per GPU of a variant run (default headline: 131072 per GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-blocks", action="store_true", help="N = 1: only the headline workload (profiling runs)")
     ap.add_argument("--contacts", action="store_true",
-                    help="headline = BASELINE.json configs[2] shape (mesh self-collision + ground plane; use with --envs 65536) "
-                         "instead of configs[1]; implied at N > 1")
+                    help="variant run: BASELINE.json configs[2] shape (mesh self-collision + ground plane; use with --envs 65536), "
+                         "no collective")
     ap.add_argument("--hull-verts", type=int, default=0,
                     help="with --contacts: OPT-IN hull simplification to at most this many vertices per hull "
                          "(changes the contact geometry; reported separately, never the parity configuration)")
@@ -369,9 +439,17 @@ def main():
                     help="BASELINE.json configs[3]: three hands in one mixed-model batch, Newton and PGS; "
                          "not the default bench line")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
     if args.mixed:
         args.envs = args.envs or 12288
         return main_mixed(args)
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain shell: start the ranks as a child process BEFORE anything here initialises the GPU (this process
+        # never becomes a rank), relay rank 0's JSON line, exit with the child's code
+        from mujoco_amd.launch import spawn_ranks
+        sys.exit(spawn_ranks(args.gpus, os.path.abspath(__file__), sys.argv[1:]))
 
     import torch
     from mujoco_amd import Model, workload
@@ -379,42 +457,69 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the product path")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: local rank {local_rank} but only {torch.cuda.device_count()} GPU(s) are visible")
     torch.cuda.set_device(local_rank)
-    dist = None
-    force_dist = bool(os.environ.get("BENCH_FORCE_DIST"))  # rehearsal of the N>1 code path with one rank
-    multi = world > 1 or force_dist
-    if multi:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
 
     model_path = os.path.join(ROOT, "tests", "golden", "dexterous_model.npz")
     seed = 1234 + 1000 * rank
     plain = not (args.contacts or args.hull_verts or args.solver != "newton" or args.envs)
+    import torch.distributed as dist
+    if plain or world > 1:
+        # one rank too goes through RCCL: the N = 1 point of the curve runs the same code as N = 8
+        if world == 1:
+            from mujoco_amd.launch import free_port
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(free_port()))
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+    else:
+        dist = None
 
-    if multi and plain:
-        # ---- N > 1: configs[4]'s shape
+    if plain:
+        # ---- headline at every N: configs[4]'s shape, 131 072 envs per GPU
         E = 131072
-        blk = contacts_block(model_path, E, local_rank, seed, args.steps, args.warmup, world, dist, world, False,
-                             "BASELINE.json configs[4] shape: DexterousDynamos.xml with STL-hull mesh self-collision + a ground "
-                             "plane at z=-0.05 (the plane is this build's augmentation, not in the reference XML), 131072 envs per "
-                             "GPU, Euler + Newton, fp64, obs/reward all-gathered over RCCL every 50 steps")
+        joined = torch.ones(1, dtype=torch.int64, device=f"cuda:{local_rank}")
+        dist.all_reduce(joined)
+        names = [None] * world
+        dist.all_gather_object(names, f"rank {rank}: cuda:{local_rank} {torch.cuda.get_device_name(local_rank)}")
+        blk, cmodel = contacts_block(model_path, E, local_rank, seed, args.steps, args.warmup, world, dist, world,
+                                     "BASELINE.json configs[4] shape, one GPU's share per rank: " + CONTACT_LABEL
+                                     + ", 131072 envs per GPU, obs/reward all-gathered over RCCL every 50 steps")
+        out = None
         if rank == 0:
             out = {"metric": "env-steps/sec", "value": blk["value"], "unit": "env-steps/s", "n_gpus": world,
                    "steps": args.steps, "warmup": args.warmup, "ms_per_step": blk["ms_per_step"],
                    "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-                   "config": blk["config"], "roofline": blk["roofline"], "reps": len(blk["wall_s_all_reps"]), "wall_s_all_reps": blk["wall_s_all_reps"],
-                   "note": "N > 1 runs configs[4]'s shape; its N = 1 point is the block contacts_131072 of the N = 1 line "
-                           "(the N = 1 headline is configs[1], a different workload)"}
+                   "config": blk["config"], "ranks_joined": int(joined.item()), "devices": names,
+                   "roofline": blk["roofline"], "reps": blk["reps"], "wall_s_all_reps": blk["wall_s_all_reps"],
+                   "note": "the same workload per GPU at every N (weak scaling): value(N) / (N x value(1)) is the scaling efficiency; "
+                           "configs[1] and configs[2] are the blocks config1_4096 / contacts_65536 of the N = 1 line"}
+        if world == 1:
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(cmodel, seconds_budget=10.0, n_steps=200)
+                try:
+                    out["cpu_baseline_allcores"] = cpu_baseline_allcores(model_path, True)
+                except Exception as ex:  # the pool is informational; the single-thread figure is the contract
+                    out["cpu_baseline_allcores"] = {"error": repr(ex)}
+            if not args.no_extra_blocks:
+                out["config1_4096"] = config1_block(model_path, 4096, local_rank, seed, args.steps, args.warmup, not args.no_cpu_baseline)
+                b2, _ = contacts_block(model_path, 65536, local_rank, seed, min(args.steps, 200), min(args.warmup, 50), 1, None, 0,
+                                       "BASELINE.json configs[2]: " + CONTACT_LABEL + ", 65536 envs, no collective")
+                if "cpu_baseline" in out:  # the same model and workload per environment as the headline's
+                    b2["cpu_baseline"] = out["cpu_baseline"]
+                    b2["cpu_baseline_allcores"] = out["cpu_baseline_allcores"]
+                out["contacts_65536"] = b2
+        if rank == 0:
             print(json.dumps(out), flush=True)
         dist.barrier()
         dist.destroy_process_group()
         return
 
-    # ---- headline workload (N = 1 default: configs[1]; flags select the variants)
+    # ---- variant runs (flags): one workload, its roofline and CPU leg; not the default line
     model = Model.load(model_path)
     if not args.contacts:
         model = workload.contact_free(model)
@@ -428,45 +533,46 @@ def main():
         model = model.copy()
         model.opt_solver = SOL_CG if args.solver == "cg" else SOL_PGS
     E = args.envs or 4096
+    multi = world > 1
     w = Workload(model, E, local_rank, seed, gather_world=world if multi else 0, dist=dist)
     m = w.measure(args.steps, args.warmup)
     stats = w.state_stats()
-    try:
-        stage = w.sim.stage_times()
-    except Exception as ex:
-        stage = {"error": str(ex)}
-    cstat, flop_env_step = (w.collision_model(stats["mean_solver_iter"]) if args.contacts else (None, FLOP_PER_ENV_STEP))
+    cstat, flop_env_step, flop_meas = (w.collision_model(stats["mean_solver_iter"]) if args.contacts
+                                       else (None, FLOP_PER_ENV_STEP, None))
 
     if rank == 0:
         wall = m["wall"]
-        chain = "k_tp_chain" in w.sim.kernel_path()[1] or "k_tpc_chain" in w.sim.kernel_path()[1]
+        path = w.sim.kernel_path()[1]
+        chain = "k_tp_chain" in path or "k_tpc_chain" in path
         kern = ("k_tp_chain" if chain else "k_tp") if args.solver == "newton" else ("k_tp_cg" if args.solver == "cg" else "k_tp_pgs")
+        hw = (None, None)
         if args.contacts:
             traffic, src = pmc_traffic("contacts_pmc_per_step" if E == 65536 and not args.hull_verts else "none",
                                        ("k_tp_col", "k_c_narrow_list", "k_tpc"))
             kern = "k_tp_col + k_c_narrow_list + " + {"newton": "k_tpc_chain" if chain else "k_tpc", "cg": "k_tpc_cg", "pgs": "k_tpc_pgs"}[args.solver]
+            if args.solver == "newton" and not args.hull_verts:
+                hw = pmc_hw_flop("contacts")
         else:
             traffic, src = pmc_traffic("config1_pmc_per_launch" if E == 4096 and args.solver == "newton" else "none", ("k_tp",))
+            if args.solver == "newton":
+                hw = pmc_hw_flop("config1")
         out = {
             "metric": "env-steps/sec", "value": E * world * args.steps / wall, "unit": "env-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall * 1e3 / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic", "reps": len(m["walls"]), "wall_s_all_reps": m["walls"],
-            "config": {"workload": "BASELINE.json configs[1]: DexterousDynamos.xml joint-space only "
+            "config": {"workload": "VARIANT RUN (not the default line) — BASELINE.json configs[1]: DexterousDynamos.xml joint-space only "
                                    "(contacts disabled), lockstep envs, random ctrl resampled every 50 steps, "
                                    "Euler + Newton, fp64",
-                       "n_envs_per_gpu": E, "n_envs_total": E * world, "ctrl_period": CTRL_PERIOD,
+                       "n_envs_per_gpu": E, "n_envs_total": E * world, "ctrl_period": CTRL_PERIOD, "kernel_path": path,
                        "collective": "RCCL all_gather obs[E,42]+reward fp32 per ctrl period" if multi else "none", **stats},
             "roofline": roofline_block(m["launches"], E, flop_env_step, kern, traffic, src,
                                        "duration = HIP events on the kernels' stream around every bs_step call of the timed regions "
-                                       "(one call = one launch of min(50, steps) steps); traffic = bytes per 50-step launch from the "
-                                       "committed PMC summary (prologue / epilogue state + outputs + spill scratch, not per-step traffic)"),
-            "stage_ms_one_step": stage,
+                                       "(contact-free: one call = one launch of min(50, steps) steps); traffic from the committed PMC summary",
+                                       flop_measured=flop_meas, hw=hw),
         }
         if cstat:
-            out["config"]["workload"] = ("BASELINE.json configs[2]: DexterousDynamos.xml with STL-hull mesh "
-                                         "self-collision + a ground plane at z=-0.05 (the plane is this build's "
-                                         "augmentation, not in the reference XML), Euler + Newton, fp64")
+            out["config"]["workload"] = "VARIANT RUN (not the default line) — BASELINE.json configs[2]: " + CONTACT_LABEL
             out["config"]["collision"] = cstat
             if args.hull_verts > 0:
                 out["config"]["workload"] += f"; OPT-IN simplified hulls (<= {args.hull_verts} vertices each): NOT the parity geometry"
@@ -480,36 +586,10 @@ def main():
                 out["cpu_baseline_allcores"] = cpu_baseline_allcores(model_path, args.contacts)
             except Exception as ex:  # the pool is informational; the single-thread figure is the contract
                 out["cpu_baseline_allcores"] = {"error": repr(ex)}
+        print(json.dumps(out), flush=True)
     w.close()
     del w
     torch.cuda.empty_cache()
-    if plain and world == 1 and not args.no_extra_blocks:
-        # ---- the north-star workloads next to the headline
-        ksteps = min(args.steps, 200)
-        kwarm = min(args.warmup, 50)
-        own_pg = False
-        b2 = contacts_block(model_path, 65536, local_rank, seed, ksteps, kwarm, 1, None, 0, not args.no_cpu_baseline,
-                            "BASELINE.json configs[2]: DexterousDynamos.xml with STL-hull mesh self-collision + a ground plane at "
-                            "z=-0.05 (the plane is this build's augmentation, not in the reference XML), 65536 envs, Euler + Newton, fp64")
-        try:
-            import torch.distributed as tdist
-            if not tdist.is_initialized():
-                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-                os.environ.setdefault("MASTER_PORT", "29577")
-                tdist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(f"cuda:{local_rank}"))
-                own_pg = True
-            b4 = contacts_block(model_path, 131072, local_rank, seed, ksteps, kwarm, 1, tdist, 1, False,
-                                "BASELINE.json configs[4], one GPU's share: the configs[2] model at 131072 envs with the per-control-"
-                                "period RCCL all-gather of obs/reward (one rank; the N = 1 point of the N > 1 runs)")
-        except Exception as ex:
-            b4 = {"error": repr(ex)}
-        if own_pg:
-            tdist.destroy_process_group()
-        if rank == 0:
-            out["contacts_65536"] = b2
-            out["contacts_131072"] = b4
-    if rank == 0:
-        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

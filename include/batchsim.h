@@ -148,8 +148,14 @@ int bs_reset_device_mask(bs_sim *s, const uint8_t *dev_mask);
  * (hipGetSymbolAddress).  Sims with more than BS_NOALLOC_MAX_ENVS environments get BS_ERR_UNSUPPORTED.
  * env_mask: host memory, n_envs bytes; if it is pinned / registered the call is fully asynchronous, a
  * pageable buffer is waited for (stream synchronisation) before the call returns.  Calls no hipMalloc /
- * hipFree / allocating routine.  Every call on a GPU shares that GPU's array: calls that overlap on one
- * GPU (two sims on different streams, two host threads) race and must be serialised by the caller. */
+ * hipFree / allocating routine (the first call on a device looks up the array's address and creates one
+ * event; make one warm-up call before a loop that must not allocate).  Every call on a GPU shares that GPU's
+ * array: the library orders the calls it is given — a call's copy into the array waits (hipStreamWaitEvent, on
+ * the device) for the previous call's reset kernels on that GPU, whichever sim and stream they ran on, and the
+ * host side of a call is under a mutex — so back-to-back calls on different sims / streams / host threads do not
+ * overwrite a mask that has not been read.  Under HIP graph capture the mask must be pinned and the call must not
+ * be the first on its device; the cross-call event is not part of a captured graph, so REPLAYS that may overlap
+ * with other resets on the same GPU are the caller's to serialise. */
 #define BS_NOALLOC_MAX_ENVS (1 << 19)
 #define BS_NOALLOC_MAX_DEVICES 64
 int bs_reset_noalloc(bs_sim *s, const uint8_t *env_mask);

@@ -1248,6 +1248,21 @@ extern "C" int bs_sim_create(const bs_model* const* models, int n_models, const 
 // which kernel family bs_step runs for this sim, and why if it is the slow generic one
 extern "C" int bs_sim_kernel_path(const bs_sim* s, char* buf, int cap) {
   if (!s || !buf || cap < 1) return fail(BS_ERR_INVALID, "bs_sim_kernel_path: null argument");
+  if (!s->parts.empty()) {
+    // mixed-model sim: the top-level handle has no model of its own; fast only if every part is, the
+    // description lists the parts ("part k: ...")
+    std::string all;
+    int fast = 1;
+    for (size_t k = 0; k < s->parts.size(); k++) {
+      char one[256];
+      const int rc = bs_sim_kernel_path(s->parts[k], one, (int)sizeof one);
+      if (rc < 0) return rc;
+      if (rc == 0) fast = 0;
+      all += (k ? "; part " : "part ") + std::to_string(k) + ": " + one;
+    }
+    snprintf(buf, (size_t)cap, "%s", all.c_str());
+    return fast;
+  }
   const bool tp = s->contacts ? s->use_tpc : s->use_tp;
   const char* kv = getenv("BS_KERNEL");
   std::string why;
@@ -1257,9 +1272,18 @@ extern "C" int bs_sim_kernel_path(const bs_sim* s, char* buf, int cap) {
     else if (s->contacts && s->cm.maxcon > TP_LPE) why = "more than 32 contacts per environment requested";
     else why = "not selected";
   }
-  snprintf(buf, (size_t)cap, "%s%s%s", tp ? (s->contacts ? (s->tp.chain && s->dm.solver == 2 ? "tree-parallel (k_tp_col, k_c_narrow_list, k_tpc_chain)" : "tree-parallel (k_tp_col, k_c_narrow_list, k_tpc)") : (s->tp.chain && s->dm.solver == 2 && s->dm.integrator == 0 ? "tree-parallel (k_tp_chain)" : "tree-parallel (k_tp)"))
-                                             : (s->contacts ? "serial (k_c_pos, k_c_broad, k_c_narrow_flat, k_c_dyn): " : "serial (k_step): "),
-           why.c_str(), "");
+  std::string fastname;
+  {
+    const char* sol = s->dm.solver == 0 ? "_pgs" : s->dm.solver == 1 ? "_cg" : "";
+    const bool chain = s->tp.chain && s->dm.solver == 2;
+    if (s->contacts)
+      fastname = std::string("tree-parallel (k_tp_col, k_c_narrow_list, k_tpc") + (chain ? "_chain" : sol) + ")";
+    else
+      fastname = std::string("tree-parallel (k_tp") + (chain && s->dm.integrator == 0 ? "_chain" : (std::string(s->dm.integrator == 1 ? "_rk4" : "") + sol).c_str()) + ")";
+  }
+  snprintf(buf, (size_t)cap, "%s%s", tp ? fastname.c_str()
+                                       : (s->contacts ? "serial (k_c_pos, k_c_broad, k_c_narrow_flat, k_c_dyn): " : "serial (k_step): "),
+           why.c_str());
   return tp ? 1 : 0;
 }
 
@@ -1423,6 +1447,11 @@ extern "C" int bs_reset_device_mask(bs_sim* s, const uint8_t* dev_mask) {
 // its own copy of the array at its own address, looked up once per device.
 static __device__ __align__(256) uint8_t scratch[BS_NOALLOC_MAX_ENVS];
 static uint8_t* g_scratch_ptr[BS_NOALLOC_MAX_DEVICES];  // device address of `scratch` per device, 0 = not looked up yet
+// one event per device, created together with the address lookup: recorded after the reset kernels that READ the
+// array, waited for by the next call's copy INTO it — so two sims on different streams of one GPU, called back
+// to back from one host thread, no longer overwrite a mask the first sim's kernel has not read yet
+static hipEvent_t g_scratch_ev[BS_NOALLOC_MAX_DEVICES];
+static bool g_scratch_ev_recorded[BS_NOALLOC_MAX_DEVICES];
 static std::mutex g_scratch_mu;
 static int scratch_on_device(int device, uint8_t** out) {
   if (device < 0 || device >= BS_NOALLOC_MAX_DEVICES)
@@ -1434,6 +1463,7 @@ static int scratch_on_device(int device, uint8_t** out) {
     uint8_t* ptr = nullptr;
     HIPCHK(hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch)));
     if (!ptr) return fail(BS_ERR_HIP, "bs_reset_noalloc: hipGetSymbolAddress returned a null address");
+    HIPCHK(hipEventCreateWithFlags(&g_scratch_ev[device], hipEventDisableTiming));
     g_scratch_ptr[device] = ptr;
   }
   *out = g_scratch_ptr[device];
@@ -1454,6 +1484,15 @@ extern "C" int bs_reset_noalloc(bs_sim* s, const uint8_t* env_mask) {
   hipPointerAttribute_t at;
   const bool pinned = hipPointerGetAttributes(&at, env_mask) == hipSuccess && at.type == hipMemoryTypeHost;
   if (!pinned) (void)hipGetLastError();
+  // stream capture: the graph's own edges order the captured nodes, and an event recorded outside the capture may
+  // not be waited for inside it — the cross-call event is skipped there (replays that overlap are the caller's to serialise)
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s->stream, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+  const bool capturing = cap != hipStreamCaptureStatusNone;
+  if (capturing && !pinned)
+    return fail(BS_ERR_INVALID, "bs_reset_noalloc: under stream capture the mask must be pinned host memory (a pageable one needs a stream synchronisation)");
+  std::lock_guard<std::mutex> lock(g_scratch_mu);  // wait + copy + launch + record of one call are not interleaved with another host thread's
+  if (!capturing && g_scratch_ev_recorded[s->device]) HIPCHK(hipStreamWaitEvent(s->stream, g_scratch_ev[s->device], 0));
   // every byte the kernels read is overwritten here, so nothing of the previous call's mask survives
   HIPCHK(hipMemcpyAsync(ptr, env_mask, (size_t)s->n_envs, hipMemcpyHostToDevice, s->stream));
   if (!pinned) HIPCHK(hipStreamSynchronize(s->stream));
@@ -1466,6 +1505,10 @@ extern "C" int bs_reset_noalloc(bs_sim* s, const uint8_t* env_mask) {
     bs_launch_reset(grid_for(s), s->stream, s->dm, s->dd, ptr);
   }
   HIPCHK(hipGetLastError());
+  if (!capturing) {
+    HIPCHK(hipEventRecord(g_scratch_ev[s->device], s->stream));
+    g_scratch_ev_recorded[s->device] = true;
+  }
   return BS_OK;
 }
 

@@ -72,3 +72,63 @@ class ObsGather:
             self._work.wait()
             self._work, self._local = None, None
         return self.out
+
+
+class ShardedBatchSim:
+    """`BatchSim(model, n_envs, device_ids=[...])` of SURVEY.md §8b for ONE process driving several GPUs: the
+    environments are split into contiguous shards (`shard_range`), one `BatchSim` per device on its own stream, no
+    traffic between them.  step / forward / reset only enqueue (the devices run concurrently), `sync`
+    waits for all.  State lives in the shards: `shards[k].data.qpos` is `[n_k, nq]` on device `device_ids[k]`,
+    `env_range[k]` its `[lo, hi)` slice of the batch; `gather(name)` / `scatter(name, value)` move a whole-batch host
+    array.  One process per GPU (`bench.py --gpus N`, torch.distributed) is the production shape; this class is the
+    single-process convenience (a device may be listed twice: two shards on one GPU)."""
+
+    def __init__(self, model, n_envs, device_ids, **kw):
+        from .sim import BatchSim
+        ids = [int(d) for d in device_ids]
+        if not ids:
+            raise ValueError("device_ids must name at least one device")
+        if n_envs < len(ids):
+            raise ValueError("fewer environments than devices")
+        self.model, self.n_envs, self.device_ids = model, int(n_envs), ids
+        self.env_range = [shard_range(self.n_envs, r, len(ids)) for r in range(len(ids))]
+        kw.setdefault("use_torch_stream", False)  # torch's current stream belongs to ONE device
+        self.shards = [BatchSim(model, n_envs=hi - lo, device_id=d, **kw) for d, (lo, hi) in zip(ids, self.env_range)]
+
+    def step(self, n=None):
+        for s in self.shards:
+            s.step(n)
+
+    def forward(self):
+        for s in self.shards:
+            s.forward()
+
+    def reset(self, env_mask=None):
+        for s, (lo, hi) in zip(self.shards, self.env_range):
+            s.reset(None if env_mask is None else env_mask[lo:hi])
+
+    def sync(self):
+        for s in self.shards:
+            s.sync()
+
+    def gather(self, name):
+        """Whole-batch host copy `[n_envs, ...]` of a `sim.data` field (synchronises every shard)."""
+        import numpy as np
+        self.sync()
+        parts = []
+        for s in self.shards:
+            t = getattr(s.data, name)
+            parts.append((t.unsqueeze(0) if s.n_envs == 1 and name not in ("time", "solver_iter", "warning", "nefc", "ncon") else t).cpu().numpy())
+        return np.concatenate(parts, axis=0)
+
+    def scatter(self, name, value):
+        import numpy as np
+        value = np.asarray(value)
+        for s, (lo, hi) in zip(self.shards, self.env_range):
+            with torch.cuda.device(s.device_id):
+                getattr(s.data, name).copy_(torch.as_tensor(value[lo:hi] if s.n_envs > 1 else value[lo]))
+            torch.cuda.current_stream(s.device_id).synchronize()  # the copy ran on torch's stream, the sim steps on its own
+
+    def close(self):
+        for s in self.shards:
+            s.close()

@@ -78,12 +78,14 @@ class HandVecEnv:
         term = torch.empty((self.n_envs, self.obs_dim), dtype=torch.float32, device=dev)
         reward = torch.empty(self.n_envs, dtype=torch.float32, device=dev)
         flags = torch.empty(self.n_envs, dtype=torch.uint8, device=dev)
+        self.sim.wait_for_torch()  # the action (and the fresh outputs' memory) belong to torch's current stream
         _abi.check(L.bs_env_pre(h, C.c_void_p(a.data_ptr()), a.shape[1]))
         self.sim.step(self.frame_skip)
         _abi.check(L.bs_env_post(h, C.c_void_p(a.data_ptr()), a.shape[1], C.c_void_p(self.t.data_ptr()), self.episode_steps,
                                  C.c_void_p(obs.data_ptr()), C.c_void_p(term.data_ptr()), self.obs_dim,
                                  C.c_void_p(reward.data_ptr()), C.c_void_p(flags.data_ptr())))
         self._keep = a  # alive until the kernels that read it have run
+        self.sim.torch_waits()  # obs / reward / flags are read on torch's current stream
         done, failed, overflow = (flags & 1) != 0, (flags & 2) != 0, (flags & 4) != 0
         info = {"terminal_obs": term, "failed": failed, "contact_overflow": overflow}
         if self.world > 1:

@@ -39,6 +39,17 @@ class _DevArray:
                                              data=(int(ptr), False), version=2)
 
 
+def _option(value, names, what):
+    """mjtSolver / mjtIntegrator number from MuJoCo's <option> name (any case) or the number itself."""
+    if isinstance(value, str):
+        if value.lower() not in names:
+            raise ValueError(f"{what} must be one of {sorted(names)} (got {value!r})")
+        return names[value.lower()]
+    if int(value) not in names.values():
+        raise ValueError(f"{what} must be one of {sorted(names.values())} (got {value!r})")
+    return int(value)
+
+
 class NativeModel:
     """Owner of a `bs_model*` handle."""
 
@@ -60,14 +71,23 @@ class NativeModel:
 
 
 class BatchData:
-    """`sim.data` — device views named after mjData members."""
+    """`sim.data` — device views named after mjData members.  The views are borrowed from the BatchSim that made
+    them (the library owns the memory): once that sim is closed or garbage-collected every access raises
+    BatchSimError, so keep the sim alive for as long as its data is used (`d = BatchSim(m).data` alone is not enough)."""
 
     def __init__(self, sim):
         # weak: sim.data <-> sim must not be a reference cycle, or `del sim` would leave the native sim (its
         # arenas and streams) alive until the cyclic collector runs
         import weakref
-        object.__setattr__(self, "_sim", weakref.proxy(sim))
+        object.__setattr__(self, "_ref", weakref.ref(sim))
         object.__setattr__(self, "_cache", {})
+
+    @property
+    def _sim(self):
+        sim = self._ref()
+        if sim is None or getattr(sim, "_h", None) is None:
+            raise BatchSimError("the BatchSim that owns this data was destroyed (sim.data is a borrowed view: keep the sim alive)")
+        return sim
 
     def _view(self, name):
         sim = self._sim
@@ -204,16 +224,35 @@ class BatchData:
 class BatchSim:
     """`MjSim(model, nsubsteps=1)` for `n_envs` environments stepped in lockstep on one GPU."""
 
-    def __init__(self, model, n_envs=1, device_id=0, nsubsteps=1, use_torch_stream=True, max_contacts=0):
+    def __init__(self, model, n_envs=1, device_id=0, nsubsteps=1, use_torch_stream=True, max_contacts=0,
+                 solver=None, integrator=None, device_ids=None):
         """`max_contacts`: cap of the contact list per environment (0 = the library's default, 32;
-        further contacts of an environment are dropped in geom-pair order and set warning bit 3, value 8)."""
+        further contacts of an environment are dropped in geom-pair order and set warning bit 3, value 8).
+        `solver` ("newton" | "cg" | "pgs") and `integrator` ("euler" | "rk4"), MuJoCo's `<option>` names in any
+        case or the mjtSolver / mjtIntegrator numbers: override `model.opt_solver` / `model.opt_integrator` for this
+        sim (what a user of the reference would choose through `Mujoco_XML.add_option`, src/Mujoco_XML.py:137-145);
+        the model passed in is left as it is.  `device_ids`: a one-element list is `device_id`; several devices in
+        one process are `mujoco_amd.dist.ShardedBatchSim` (one sim per device), several processes `bench.py --gpus N`."""
         if n_envs < 1:
             raise ValueError("n_envs must be >= 1")
         if max_contacts < 0:
             raise ValueError("max_contacts must be >= 0")
         if nsubsteps < 1:
             raise ValueError("nsubsteps must be >= 1")
+        if device_ids is not None:
+            ids = [int(x) for x in device_ids]
+            if len(ids) != 1:
+                raise ValueError("BatchSim runs on one device: for several use mujoco_amd.dist.ShardedBatchSim(model, n_envs, "
+                                 "device_ids=[...]) (one process) or one process per GPU (bench.py --gpus N)")
+            device_id = ids[0]
         L = _abi.lib()
+        if solver is not None or integrator is not None:
+            base = model.model if isinstance(model, NativeModel) else model
+            model = base.copy()
+            if solver is not None:
+                model.opt_solver = _option(solver, {"pgs": 0, "cg": 1, "newton": 2}, "solver")
+            if integrator is not None:
+                model.opt_integrator = _option(integrator, {"euler": 0, "rk4": 1}, "integrator")
         self.model = model
         self.n_envs = int(n_envs)
         self.device_id = int(device_id)
@@ -256,6 +295,30 @@ class BatchSim:
     def __exit__(self, *a):
         self.close()
 
+    # -- stream ordering between the caller's torch stream and the sim's stream.  With the default
+    # use_torch_stream=True they are the same stream and both calls are no-ops; with the sim's own stream (or after
+    # the caller switched torch streams) device tensors handed to the library were produced on ANOTHER stream than
+    # the one its kernels run on, so the sim's stream waits for the producer first, and consumers wait for the sim.
+    def _streams(self):
+        import torch
+        cur = torch.cuda.current_stream(self.device_id)
+        sh = self.stream_handle()
+        if sh == cur.cuda_stream:
+            return None, None
+        return cur, torch.cuda.ExternalStream(sh, device=f"cuda:{self.device_id}")
+
+    def wait_for_torch(self):
+        """The sim's stream waits for what torch's current stream has enqueued so far (inputs: masks, actions, state)."""
+        cur, mine = self._streams()
+        if cur is not None:
+            mine.wait_stream(cur)
+
+    def torch_waits(self):
+        """torch's current stream waits for what the sim's stream has enqueued so far (outputs: obs, reward, views)."""
+        cur, mine = self._streams()
+        if cur is not None:
+            cur.wait_stream(mine)
+
     # -- MjSim surface
     def step(self, n=None):
         _abi.check(_abi.lib().bs_step(self._h, self.nsubsteps if n is None else int(n)))
@@ -273,8 +336,10 @@ class BatchSim:
             mk = env_mask.to(torch.uint8).contiguous()
             if tuple(mk.shape) != (self.n_envs,):
                 raise ValueError("env_mask must have shape (n_envs,)")
+            self.wait_for_torch()  # the mask was written on torch's current stream
             _abi.check(_abi.lib().bs_reset_device_mask(self._h, C.c_void_p(mk.data_ptr())))
             self._keep_mask = mk  # alive until the kernel has read it (stream order: freed memory is reused in order)
+            self.torch_waits()
         else:
             mk = np.ascontiguousarray(np.asarray(env_mask).astype(np.uint8))
             if mk.shape != (self.n_envs,):
@@ -310,7 +375,9 @@ class BatchSim:
         import torch
         m = self.model
         buf = torch.empty((self._state_rows(), self.n_envs), dtype=torch.float64, device=f"cuda:{self.device_id}")
+        self.wait_for_torch()  # the buffer's memory may still be in use by earlier work of torch's stream
         _abi.check(_abi.lib().bs_get_state(self._h, C.c_void_p(buf.data_ptr()), self.n_envs))
+        self.torch_waits()
         nq, nv = m.nq, m.nv
         cut = [0, 1, 1 + nq, 1 + nq + nv, 1 + nq + 2 * nv, 1 + nq + 3 * nv]
         t, q, v, a, w = [buf[cut[i]:cut[i + 1]].T for i in range(5)]
@@ -329,7 +396,9 @@ class BatchSim:
         E, dev = self.n_envs, f"cuda:{self.device_id}"
         if buf is None or tuple(buf.shape) != (self._state_rows(), E):
             buf = torch.empty((self._state_rows(), E), dtype=torch.float64, device=dev)
+            self.wait_for_torch()
             _abi.check(_abi.lib().bs_get_state(self._h, C.c_void_p(buf.data_ptr()), E))
+            self.torch_waits()
         else:
             buf = buf.clone()  # the caller may have edited the views
         m = self.model
@@ -343,13 +412,14 @@ class BatchSim:
             rows = cut[i + 1] - cut[i]
             val = val.reshape(E, rows) if val.numel() == E * rows else val.reshape(1, -1).expand(E, rows)
             buf[cut[i]:cut[i + 1]].copy_(val.T)
+        self.wait_for_torch()  # the buffer was filled on torch's current stream
         _abi.check(_abi.lib().bs_set_state(self._h, C.c_void_p(buf.data_ptr()), E))
         self._keep_state = buf  # alive until the copies have run
 
     def kernel_path(self):
         """(fast, description): which kernel family bs_step runs for this sim (bs_sim_kernel_path)."""
-        buf = C.create_string_buffer(256)
-        rc = _abi.lib().bs_sim_kernel_path(self._h, buf, 256)
+        buf = C.create_string_buffer(1024)
+        rc = _abi.lib().bs_sim_kernel_path(self._h, buf, 1024)
         if rc < 0:
             _abi.check(rc)
         return bool(rc), buf.value.decode()
@@ -441,6 +511,11 @@ class MixedBatchSim(BatchSim):
         self._part_model = [int(k) for k in sorted(set(ids.tolist()))]
         self.parts = [_Part(self, i) for i in range(L.bs_sim_num_parts(self._h))]
         self.data = None  # fields live in the parts
+        fast, path = self.kernel_path()
+        if not fast:
+            import warnings
+            warnings.warn("mujoco_amd: a part of this mixed-model batch runs on the generic one-environment-per-lane kernels, "
+                          "about 40x slower than the tree-parallel ones: " + path, RuntimeWarning, stacklevel=2)
         if use_torch_stream:
             import torch
             with torch.cuda.device(self.device_id):

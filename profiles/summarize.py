@@ -8,7 +8,7 @@ import glob
 import json
 import shutil
 
-ROUND = "r02"
+ROUND = "r03"
 
 
 def agg(d):
@@ -38,7 +38,7 @@ def stats(d, dst):
 out = {"config1_kernel_stats": stats("p_tp_stats", f"profiles/{ROUND}_tp_kernel_stats.csv"),
        "contacts_kernel_stats": stats("p_c_stats", f"profiles/{ROUND}_contacts_kernel_stats.csv")}
 for tag, ds in (("config1_pmc_per_launch", ["p_tp_fetch", "p_tp_write", "p_tp_sq", "p_tp_sq2"]),
-                ("contacts_pmc_per_launch", ["p_c_fetch", "p_c_write", "p_c_sq", "p_c_mem"])):
+                ("contacts_pmc_per_launch", ["p_c_fetch", "p_c_write", "p_c_sq", "p_c_sq2", "p_c_mem"])):
     m = collections.defaultdict(dict)
     for d in ds:
         for k, v in agg(d).items():
@@ -48,8 +48,24 @@ for tag, ds in (("config1_pmc_per_launch", ["p_tp_fetch", "p_tp_write", "p_tp_sq
 # 21 800 envs at 65 536): per-step traffic = 3 x the per-launch averages
 out["contacts_pmc_per_step"] = {k: {a: 3 * b for a, b in v.items() if a in ("FETCH_SIZE", "WRITE_SIZE")}
                                 for k, v in out["contacts_pmc_per_launch"].items() if k in ("k_tp_col", "k_c_narrow_list", "k_tpc")}
-out["notes"] = ("per-launch averages over all dispatches of the kernel; k_tp / k_tpc stand for the chain instantiations k_tp_chain / k_tpc_chain that this model runs. config1 = `python3 bench.py --steps 500 --warmup 100 "
-                "--no-cpu-baseline --no-extra-blocks` (k_tp: 50 steps x 4096 envs per launch); contacts = `python3 bench.py --contacts --envs 65536 "
+
+
+
+def hw_flop(k):
+    """fp64 flop ISSUED per launch: wavefront instructions x 64 lanes (masked lanes included), FMA = 2."""
+    return 64.0 * (2 * k.get("SQ_INSTS_VALU_FMA_F64", 0.0) + k.get("SQ_INSTS_VALU_ADD_F64", 0.0)
+                   + k.get("SQ_INSTS_VALU_MUL_F64", 0.0) + k.get("SQ_INSTS_VALU_TRANS_F64", 0.0))
+
+
+# hardware-counted fp64 work per env-step (bench.py's roofline.hw_fp64_frac = this x env-steps/s / 78.6 TFLOP/s):
+# config1: one k_tp launch = 50 steps x 4096 envs; contacts: one launch of each kernel per range of 65 536 / 3 envs
+cpl = out["contacts_pmc_per_launch"]
+out["hw_fp64_flop_per_env_step"] = {
+    "config1": hw_flop(out["config1_pmc_per_launch"]["k_tp"]) / (4096 * 50),
+    "contacts": sum(hw_flop(cpl[k]) for k in ("k_tp_col", "k_c_narrow_list", "k_tpc") if k in cpl) / (65536 / 3.0),
+    "contacts_per_kernel": {k: hw_flop(cpl[k]) / (65536 / 3.0) for k in ("k_tp_col", "k_c_narrow_list", "k_tpc") if k in cpl}}
+out["notes"] = ("per-launch averages over all dispatches of the kernel; k_tp / k_tpc stand for the chain instantiations k_tp_chain / k_tpc_chain that this model runs. config1 = `python3 bench.py --envs 4096 --steps 500 --warmup 100 "
+                "--no-cpu-baseline` (k_tp: 50 steps x 4096 envs per launch); contacts = `python3 bench.py --contacts --envs 65536 "
                 "--steps 50 --warmup 50 --no-cpu-baseline` (one step per launch, three ranges of about 21 800 envs on three streams). "
                 "FETCH_SIZE / WRITE_SIZE in KB as rocprofv3 reports them; HBM-side traffic estimate = (2 x FETCH_SIZE + "
                 "WRITE_SIZE) x 1024 B (gfx950 FETCH_SIZE halving, MI355X_MICROARCH.md; strided 8-byte accesses are "

@@ -145,3 +145,61 @@ def test_allgather_obs_world2_gloo(tmp_path):
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert (tmp_path / "ok_0").exists() and (tmp_path / "ok_1").exists()
+
+
+_RANK_SCRIPT = r"""
+import argparse, json, os, sys
+import torch, torch.distributed as dist
+ap = argparse.ArgumentParser()
+ap.add_argument("--gpus", type=int)
+ap.add_argument("--fail-rank", type=int, default=-1)
+a = ap.parse_args()
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+assert world == a.gpus == int(os.environ["WORLD_SIZE"])
+one = torch.ones(1, dtype=torch.int64)
+dist.all_reduce(one)
+if rank == a.fail_rank:
+    sys.exit(3)
+if rank == 0:
+    print(json.dumps({"n_gpus": world, "ranks_joined": int(one.item())}), flush=True)
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_spawn_ranks_from_a_plain_shell_gloo(tmp_path, monkeypatch):
+    """`bench.py --gpus N` without WORLD_SIZE starts its own ranks through mujoco_amd.launch.spawn_ranks: rehearsed
+    here with a two-rank gloo script (rank 0's JSON line is relayed, a failing rank makes the exit code non-zero,
+    rank variables of an outer launcher do not leak into the child)."""
+    import io
+    import json
+    from mujoco_amd.launch import spawn_ranks
+    script = tmp_path / "r.py"
+    script.write_text(_RANK_SCRIPT)
+    monkeypatch.setenv("WORLD_SIZE", "7")  # must not reach the ranks
+    monkeypatch.setenv("RANK", "5")
+    buf = io.StringIO()
+    rc = spawn_ranks(2, script, ["--gpus", "2"], out=buf, timeout=300)
+    assert rc == 0, buf.getvalue()
+    line = [ln for ln in buf.getvalue().splitlines() if ln.startswith("{")]
+    assert len(line) == 1 and json.loads(line[0]) == {"n_gpus": 2, "ranks_joined": 2}
+    buf = io.StringIO()
+    assert spawn_ranks(2, script, ["--gpus", "2", "--fail-rank", "1"], out=buf, timeout=300) != 0
+
+
+def test_bench_gpus_2_launches_two_ranks_itself(tmp_path):
+    """From a plain shell `python bench.py --gpus 2` becomes a launcher (no GPU here: both ranks refuse to run
+    without an MI355X, and the parent exits non-zero with their message on stderr instead of silently running one rank)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("rehearsal for the GPU-less container")
+    assert r.returncode != 0
+    assert r.stderr.count("bench.py needs an MI355X") >= 2, r.stderr[-2000:]
+    # under a launcher whose world size contradicts --gpus the rank refuses instead of running a different job
+    env["WORLD_SIZE"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr

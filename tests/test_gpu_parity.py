@@ -143,6 +143,47 @@ def test_default_state_golden(hand_model):
         assert np.abs(sim.data.qvel.cpu().numpy() - g["qvel"][k]).max() <= 1e-5
 
 
+def test_config0_as_shipped_contacts_on(hand_model):
+    """BASELINE.json configs[0] AS THE REFERENCE SHIPS IT: /root/reference/output/DexterousDynamos.xml:4 gives
+    every mesh geom contype = conaffinity = 1, so `MjSim(model).step()` x 1000 runs self-collision (no plane).
+    Single environment (half-empty wavefront), default state, zero ctrl, default kernel path
+    (k_tp_col -> k_c_narrow_list -> k_tpc_chain) against the committed oracle trajectory: qpos <= 1e-6,
+    contact sets exact, the nine limit rows of SURVEY.md section 8d config 1 active at step 0."""
+    import os
+    from conftest import GOLDEN
+    from mujoco_amd import BatchSim
+    g = np.load(os.path.join(GOLDEN, "dexterous_default_contacts_traj.npz"))
+    rows = {int(r[0]): r for r in g["rows"]}
+    sim = BatchSim(hand_model, n_envs=1)
+    assert sim.kernel_path()[0] and "k_tpc" in sim.kernel_path()[1]
+
+    def check_rows(step):
+        want = g[f"contacts_step{step}"]
+        got = sorted(sim.data.contacts(0))
+        assert [(a, b) for a, b, _ in got] == [(int(a), int(b)) for a, b, _ in want], step
+        assert np.abs(np.array([d for _, _, d in got]) - want[:, 2]).max() < 1e-9
+        nefc, ncon = int(sim.data.nefc.cpu().numpy().ravel()[0]), int(sim.data.ncon.cpu().numpy().ravel()[0])
+        assert nefc == int(rows[step][1]) and ncon == int(rows[step][5])
+        return nefc, ncon
+
+    sim.step(1)
+    sim.sync()
+    nefc, ncon = check_rows(1)
+    assert nefc - 4 - 21 - 4 * ncon == 9  # the nine joints that sit on a range end at qpos = 0
+    sim.step(99)
+    sim.sync()
+    check_rows(100)
+    for k in range(10):
+        if k:
+            sim.step(100)
+            sim.sync()
+        assert np.abs(sim.data.qpos.cpu().numpy() - g["qpos"][k]).max() <= 1e-6, k
+        assert np.abs(sim.data.qvel.cpu().numpy() - g["qvel"][k]).max() <= 1e-5, k
+    check_rows(1000)
+    assert int(sim.data.warning.cpu().numpy().ravel()[0]) == 0
+    assert abs(float(sim.data.time.cpu().numpy().ravel()[0]) - 2.0) < 1e-9
+
+
 def test_rk4_matches_oracle(hand_model):
     import torch
     from mujoco_amd import BatchSim, workload

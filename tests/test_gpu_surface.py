@@ -277,6 +277,108 @@ def test_kernel_path_is_reported_and_fallback_warns(hand_model, monkeypatch):
     monkeypatch.delenv("BS_KERNEL")
 
 
+def test_solver_and_integrator_kwargs(hand_model):
+    """`BatchSim(model, n_envs, solver=, integrator=)` override model.opt_* for this sim (the
+    choice a user of the reference makes through Mujoco_XML.add_option, src/Mujoco_XML.py:137-145); the model passed
+    in is untouched, the kernel that runs is the solver's, and the result equals a sim built from an edited model."""
+    import torch
+    from mujoco_amd import BatchSim, workload
+    from mujoco_amd.model import INT_RK4, SOL_NEWTON, SOL_PGS
+    free = workload.contact_free(hand_model)
+    E = 66
+    q, v = workload.config2_state(free, E, seed=8)
+    c = workload.config2_ctrl(free, E, seed=8)
+
+    def run(sim):
+        sim.data.qpos.copy_(torch.as_tensor(q)); sim.data.ctrl.copy_(torch.as_tensor(c))
+        sim.step(5); sim.sync()
+        out = sim.data.qpos.clone(), sim.data.qacc.clone()
+        sim.close()
+        return out
+
+    sim = BatchSim(free, n_envs=E, solver="pgs")
+    assert sim.kernel_path() == (True, "tree-parallel (k_tp_pgs)") and sim.model.opt_solver == SOL_PGS
+    assert free.opt_solver == SOL_NEWTON  # the caller's model is left as it was
+    a = run(sim)
+    edited = free.copy(); edited.opt_solver = SOL_PGS
+    b = run(BatchSim(edited, n_envs=E))
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    sim = BatchSim(free, n_envs=E, solver="CG", integrator="RK4")
+    assert sim.kernel_path() == (True, "tree-parallel (k_tp_rk4_cg)") and sim.model.opt_integrator == INT_RK4
+    sim.close()
+    sim = BatchSim(hand_model, n_envs=E, solver=0)  # mjtSolver numbers work too: PGS with contacts
+    assert sim.kernel_path() == (True, "tree-parallel (k_tp_col, k_c_narrow_list, k_tpc_pgs)")
+    sim.close()
+    sim = BatchSim(free, n_envs=E, device_ids=[0])
+    assert sim.device_id == 0 and sim.kernel_path()[1] == "tree-parallel (k_tp_chain)"
+    sim.close()
+    for bad in (dict(solver="sor"), dict(integrator="implicit"), dict(solver=5), dict(device_ids=[0, 0])):
+        with pytest.raises(ValueError):
+            BatchSim(free, n_envs=E, **bad)
+
+
+def test_data_of_a_destroyed_sim_raises_clearly(hand_model):
+    """`sim.data` is a borrowed view: after the sim is closed or collected an access raises BatchSimError, not a bare
+    ReferenceError or a use of freed device memory."""
+    from mujoco_amd import BatchSim, BatchSimError, workload
+    free = workload.contact_free(hand_model)
+    d = BatchSim(free, n_envs=4).data  # the sim is collected at once
+    import gc
+    gc.collect()
+    with pytest.raises(BatchSimError, match="destroyed"):
+        d.qpos
+    sim = BatchSim(free, n_envs=4)
+    d = sim.data
+    assert d.qpos.shape == (4, free.nq)
+    sim.close()
+    with pytest.raises(BatchSimError, match="destroyed"):
+        d.contacts(0)
+
+
+def test_mixed_kernel_path_aggregates_parts(hand_model, monkeypatch):
+    """bs_sim_kernel_path on a mixed-model handle (it dereferenced the top-level sim's null model): one
+    description per part, fast only if every part is; MixedBatchSim warns when a part is on the serial kernels."""
+    from mujoco_amd import MixedBatchSim, workload
+    a = workload.contact_free(hand_model)
+    b = a.copy(); b.dof_damping = b.dof_damping * 2.0
+    sim = MixedBatchSim([a, b], counts=[6, 5])
+    fast, path = sim.kernel_path()
+    assert fast and path.count("k_tp_chain") == 2 and "part 0:" in path and "part 1:" in path
+    sim.close()
+    monkeypatch.setenv("BS_KERNEL", "serial")
+    with pytest.warns(RuntimeWarning, match="generic one-environment-per-lane"):
+        sim = MixedBatchSim([a, b], counts=[6, 5])
+    fast, path = sim.kernel_path()
+    assert not fast and path.count("BS_KERNEL=serial") == 2
+    sim.close()
+    monkeypatch.delenv("BS_KERNEL")
+
+
+def test_sharded_batch_sim_two_shards_one_device(hand_model):
+    """`device_ids=[...]` in one process (mujoco_amd.dist.ShardedBatchSim): contiguous shards, one sim per entry, no
+    traffic between them.  One GPU here, so both shards sit on device 0 — the result must equal the unsharded batch."""
+    import torch
+    from mujoco_amd import BatchSim, workload
+    from mujoco_amd.dist import ShardedBatchSim
+    E = 131
+    q, v = workload.config2_state(hand_model, E, seed=21)
+    c = workload.config2_ctrl(hand_model, E, seed=21)
+    sh = ShardedBatchSim(hand_model, E, device_ids=[0, 0])
+    assert sh.env_range == [(0, 66), (66, 131)] and [s.n_envs for s in sh.shards] == [66, 65]
+    sh.scatter("qpos", q); sh.scatter("ctrl", c)
+    sh.step(4)
+    one = BatchSim(hand_model, n_envs=E)
+    one.data.qpos.copy_(torch.as_tensor(q)); one.data.ctrl.copy_(torch.as_tensor(c))
+    one.step(4); one.sync()
+    assert np.array_equal(sh.gather("qpos"), one.data.qpos.cpu().numpy())
+    assert np.array_equal(sh.gather("ncon"), one.data.ncon.cpu().numpy()) and sh.gather("ncon").sum() > 0
+    mask = np.zeros(E, dtype=np.uint8); mask[[0, 65, 66, 130]] = 1
+    sh.reset(mask)
+    t = sh.gather("time")
+    assert (t[mask == 1] == 0).all() and (t[mask == 0] > 0).all()
+    sh.close(); one.close()
+
+
 @pytest.mark.parametrize("solver", ["newton", "cg"])
 def test_forward_with_contacts_writes_every_intermediate_on_tp_kernels(hand_model, solver):
     """bs_forward of a contact model on the tree-parallel path (k_tp_col, narrowphase, k_tpc_full[_cg]): the

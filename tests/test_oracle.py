@@ -194,6 +194,32 @@ def test_committed_trajectory_fixture(cf_model):
         assert np.abs(s.qvel - g["qvel"][k]).max() < 1e-11
 
 
+def test_config0_as_shipped_fixture(hand_model):
+    """BASELINE.json configs[0] as the reference ships it (output/DexterousDynamos.xml:4: every mesh geom
+    contype = conaffinity = 1, so self-collision is ON): default state, zero ctrl, 1000 steps.  The oracle
+    reproduces its committed trajectory; the structural facts of SURVEY.md section 8d config 1 hold: nine
+    limit rows active at step 0, four equalities, 21 frictionloss rows."""
+    g = np.load(os.path.join(GOLDEN, "dexterous_default_contacts_traj.npz"))
+    assert hand_model.npair == 210 and not (hand_model.opt_disableflags & 16)
+    s = OracleSim(hand_model)
+    rows = {int(r[0]): r for r in g["rows"]}
+    for k in range(1000):
+        s.step()
+        if k + 1 in rows:
+            d = s._d.contents
+            assert [d.nefc, d.ne, d.nf, d.nl, d.ncon] == [int(x) for x in rows[k + 1][1:6]]
+            got = sorted((c["geom1"], c["geom2"], c["dist"]) for c in s.contacts())
+            want = g[f"contacts_step{k + 1}"]
+            assert [(a, b) for a, b, _ in got] == [(int(a), int(b)) for a, b, _ in want]
+            assert np.abs(np.array([x[2] for x in got]) - want[:, 2]).max() < 1e-12
+        if (k + 1) % 100 == 0:
+            assert np.abs(s.qpos - g["qpos"][k // 100]).max() < 1e-12
+            assert np.abs(s.qvel - g["qvel"][k // 100]).max() < 1e-11
+    r1 = rows[1]
+    assert (int(r1[2]), int(r1[3]), int(r1[4])) == (4, 21, 9)  # equalities, frictionloss, the nine limits at qpos = 0
+    assert int(r1[1]) == 4 + 21 + 9 + 4 * int(r1[5])
+
+
 def test_nan_guard_resets(cf_model):
     s = OracleSim(cf_model)
     s.qpos[2] = np.nan

@@ -77,3 +77,39 @@ def test_reset_noalloc_matches_reset(hand_model):
     big.close()
     with pytest.raises(BatchSimError):
         _abi.check(L.bs_reset_noalloc(a._h, None))
+
+
+def test_reset_noalloc_two_sims_on_two_streams(hand_model):
+    """Two sims on their OWN streams (use_torch_stream=False), pinned masks, calls issued back to back from one host
+    thread: the second call's copy into the shared scratch array waits on the device for the first sim's reset kernel
+    (per-device event), so neither mask is overwritten before it has been read."""
+    import torch
+    from mujoco_amd import BatchSim, workload
+    m = workload.contact_free(hand_model)
+    rng = np.random.default_rng(11)
+    EA, EB = 200_000, 4_096
+    q = {E: workload.config2_state(m, E, seed=E)[0] for E in (EA, EB)}
+    masks = {E: torch.as_tensor((rng.random(E) < 0.5).astype(np.uint8)).pin_memory() for E in (EA, EB)}
+    sims = {}
+    for kind in ("ref", "noalloc"):
+        for E in (EA, EB):
+            s = BatchSim(m, n_envs=E, use_torch_stream=False)
+            s.data.qpos.copy_(torch.as_tensor(q[E]))
+            torch.cuda.synchronize()
+            s.step(2)
+            sims[kind, E] = s
+    assert sims["noalloc", EA].stream_handle() != sims["noalloc", EB].stream_handle()
+    for rep in range(3):
+        for E in (EA, EB):
+            sims["ref", E].reset(masks[E].numpy())
+        sims["noalloc", EA].reset_noalloc(masks[EA])   # back to back, different streams, no host wait in between
+        sims["noalloc", EB].reset_noalloc(masks[EB])
+        for s in sims.values():
+            s.step(1)
+    for s in sims.values():
+        s.sync()
+    for E in (EA, EB):
+        for f in ("qpos", "qvel", "time"):
+            assert torch.equal(getattr(sims["ref", E].data, f), getattr(sims["noalloc", E].data, f)), (E, f)
+    for s in sims.values():
+        s.close()
