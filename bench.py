@@ -123,7 +123,7 @@ def cpu_baseline_allcores(model_path, contacts=False):
     share = os.environ.get("OMP_NUM_THREADS")
     cores = min(os.cpu_count() or 1, int(share)) if share and share.isdigit() else (os.cpu_count() or 1)
     cores = max(1, min(cores, 64))
-    n_envs, n_steps = (100, 200) if contacts else (400, 1000)   # a few seconds per worker
+    n_envs, n_steps = (400, 200) if contacts else (400, 1000)   # a few seconds per worker
     ctx = mp.get_context("spawn")
     t0 = time.perf_counter()
     with ctx.Pool(cores) as pool:
@@ -307,6 +307,7 @@ def contacts_block(model_path, E, local_rank, seed, steps, warmup, world, dist, 
     blk = {"value": E * world * steps / m["wall"], "unit": "env-steps/s", "ms_per_step": m["wall"] * 1e3 / steps,
            "steps": steps, "reps": len(m["walls"]), "wall_s_all_reps": m["walls"],
            "config": {"workload": label, "n_envs_per_gpu": E, "n_envs_total": E * world, "ctrl_period": CTRL_PERIOD,
+                      "device_memory": w.sim.footprint(),
                       "collective": ("RCCL all_gather obs[E,42]+reward fp32 per ctrl period, overlapped with the next steps"
                                      if gather_world else "none"),
                       "kernel_path": path, "collision": cstat, **stats},
@@ -338,7 +339,7 @@ def config1_block(model_path, E, local_rank, seed, steps, warmup, with_cpu):
            "config": {"workload": "BASELINE.json configs[1]: DexterousDynamos.xml joint-space only (contacts disabled), lockstep "
                                   "envs, random ctrl resampled every 50 steps, Euler + Newton, fp64",
                       "n_envs_per_gpu": E, "n_envs_total": E, "ctrl_period": CTRL_PERIOD, "collective": "none",
-                      "kernel_path": path, **stats},
+                      "device_memory": w.sim.footprint(), "kernel_path": path, **stats},
            "roofline": roofline_block(m["launches"], E, FLOP_PER_ENV_STEP, kern, traffic, src,
                                       "duration = HIP events on the kernels' stream around every bs_step call of the timed regions "
                                       "(one call = one launch of min(50, steps) steps); traffic = bytes per 50-step launch from the "
@@ -565,6 +566,7 @@ def main():
                                    "(contacts disabled), lockstep envs, random ctrl resampled every 50 steps, "
                                    "Euler + Newton, fp64",
                        "n_envs_per_gpu": E, "n_envs_total": E * world, "ctrl_period": CTRL_PERIOD, "kernel_path": path,
+                       "device_memory": w.sim.footprint(),
                        "collective": "RCCL all_gather obs[E,42]+reward fp32 per ctrl period" if multi else "none", **stats},
             "roofline": roofline_block(m["launches"], E, flop_env_step, kern, traffic, src,
                                        "duration = HIP events on the kernels' stream around every bs_step call of the timed regions "

@@ -70,9 +70,13 @@ typedef struct bs_model_desc {
 } bs_model_desc;
 
 typedef struct bs_options {
-  int32_t max_contacts_per_env; /* cap for the compacted contact list (0 = default 32) */
+  int32_t max_contacts_per_env; /* cap for the compacted contact list (0 = default 32; up to 32 the 32-lane tree-parallel
+                                   kernels run, up to 64 the wide ones — one environment per wavefront, about half the
+                                   throughput —, beyond that the generic one-environment-per-lane kernels) */
   int32_t nsubsteps_hint;       /* informational */
-  int32_t reserved[6];
+  const int32_t *max_contacts_per_model; /* nullable; mixed-model sims: one cap per model (0 = max_contacts_per_env), so
+                                            that only the model that needs a longer list pays for the wide kernels */
+  int32_t reserved[4];
 } bs_options;
 
 typedef struct bs_model bs_model;
@@ -174,6 +178,14 @@ int bs_set_state(bs_sim *s, const double *dev_buf, int64_t ld);
  * above 6, ...), < 0 (a bs_status) on error.  No counterpart in the reference (MuJoCo has one code path);
  * mujoco_amd.BatchSim warns once when the answer is 0. */
 int bs_sim_kernel_path(const bs_sim *s, char *buf, int cap);
+/* Device memory the sim holds, in bytes per arena: out[0] state arena (every [rows][E_pad] field of bs_get_ptr
+ * and the intermediates of the generic kernels), out[1] contact arena (candidate + contact lists, narrowphase
+ * work list), out[2] geom-frame records of the persistent narrowphase, out[3] buffers of the serial contact solver
+ * (0 until bs_stage_times or an ineligible model needs them), out[4] = E_pad (n_envs rounded up to 64; a mixed
+ * sim: summed over its parts, like the bytes).  When an arena does not fit, bs_sim_create fails with BS_ERR_NOMEM
+ * and a message that names the arena, its bytes per environment and the total.  No counterpart in mujoco-py
+ * (mjData is one host allocation per environment); used to size batches against the 288 GB of an MI355X. */
+int bs_sim_footprint(const bs_sim *s, int64_t out[5]);
 /* The stream the sim's kernels are enqueued on (its own, or the one given to bs_set_stream). */
 int bs_get_stream(bs_sim *s, void **hip_stream);
 

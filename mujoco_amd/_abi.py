@@ -40,7 +40,7 @@ class ModelDesc(C.Structure):
 
 
 class Options(C.Structure):
-    _fields_ = [("max_contacts_per_env", _I), ("nsubsteps_hint", _I), ("reserved", _I * 6)]
+    _fields_ = [("max_contacts_per_env", _I), ("nsubsteps_hint", _I), ("max_contacts_per_model", _IP), ("reserved", _I * 4)]
 
 
 # enum bs_field
@@ -54,7 +54,7 @@ FIELD_ID = {n: i for i, n in enumerate(FIELD_NAMES)}
 SYMBOLS = ("bs_version bs_last_error bs_device_count bs_model_create bs_model_destroy bs_sim_create "
            "bs_sim_destroy bs_set_stream bs_step bs_forward bs_reset bs_get_ptr bs_copy_field "
            "bs_get_contacts bs_collision_stats bs_sync bs_stage_times bs_timed_steps bs_sim_num_parts bs_sim_part bs_pack_obs "
-           "bs_reset_device_mask bs_state_rows bs_get_state bs_set_state bs_get_stream bs_get_contact_geometry bs_reset_noalloc bs_sim_kernel_path bs_env_pre bs_env_post").split()
+           "bs_reset_device_mask bs_state_rows bs_get_state bs_set_state bs_get_stream bs_get_contact_geometry bs_reset_noalloc bs_sim_kernel_path bs_env_pre bs_env_post bs_sim_footprint").split()
 
 
 class BatchSimError(RuntimeError):
@@ -102,6 +102,7 @@ def lib():
     L.bs_set_state.argtypes = [vp, vp, C.c_int64]
     L.bs_get_stream.argtypes = [vp, C.POINTER(vp)]
     L.bs_sim_kernel_path.argtypes = [vp, C.c_char_p, C.c_int]
+    L.bs_sim_footprint.argtypes = [vp, C.POINTER(C.c_int64)]
     L.bs_env_pre.argtypes = [vp, vp, C.c_int64]
     L.bs_env_post.argtypes = [vp, vp, C.c_int64, vp, C.c_int, vp, vp, C.c_int64, vp, vp]
     L.bs_get_contact_geometry.argtypes = [vp, C.c_int64, _DP, _DP, C.c_int, C.POINTER(C.c_int)]

@@ -58,7 +58,7 @@ struct DeviceImage {
   int device = -1;
   void* blob = nullptr;
   DevModel dm;
-  TpModel tp;
+  TpModel tp[2];  // 32-lane and wide tables
   ColModel cm;
 };
 
@@ -70,25 +70,34 @@ struct bs_model {
   std::vector<int32_t> eq_dof1, eq_dof2, eq_jnt1, eq_jnt2, eq_Hadr, fric_dof, lim_jnt;
   std::vector<double> eq_data, eq_solref, eq_solimp;
   int damped = 0, hess_sparse = 1;
-  // tree-parallel kernel (physics_tp.h): per-lane table and eligibility
-  int tp_ok = 0;
-  std::string tp_why;
-  std::vector<int32_t> tp_table;  // [TPI_TOTAL][32]
-  std::vector<double> tp_dtable;  // [TPD_TOTAL][32]
-  std::vector<double> tp_ktable;  // [32][TPK_N]
-  std::vector<int32_t> tp_pgs;    // PGS sweep order (TpModel::pgs_order)
-  TpModel tp;
+  // tree-parallel kernels (physics_tp.h): per-lane tables and eligibility, for the 32-lane build (two environments
+  // per wavefront, nbody <= 31) and the wide 64-lane build (one environment per wavefront, nbody <= 63)
+  struct TpHost {
+    int lpe = 32;
+    int tp_ok = 0;
+    std::string tp_why;
+    std::vector<int32_t> tp_table;  // [TPI_TOTAL][lpe]
+    std::vector<double> tp_dtable;  // [TPD_TOTAL][lpe]
+    std::vector<double> tp_ktable;  // [lpe][TPK_N]
+    std::vector<int32_t> tp_pgs;    // PGS sweep order (TpModel::pgs_order)
+    TpModel tp;
+  } tpv[2];
   std::vector<DeviceImage> images;
 };
 
 // Decide whether the tree-parallel kernel can run this model and build its lane table.
-static void build_tp(bs_model* m) {
-  const bs_model_desc& s = m->d;
+static void build_tp(bs_model* mdl, int variant) {
+  const bs_model_desc& s = mdl->d;
+  bs_model::TpHost* const m = &mdl->tpv[variant];
+  const int LPE = variant ? 64 : 32;  // lanes per environment of this variant's kernels (their compile-time TP_LPE)
+  m->lpe = LPE;
   const int nb = s.nbody, nv = s.nv, nu = s.nu;
   m->tp_ok = 0;
   memset(&m->tp, 0, sizeof m->tp);
   auto no = [&](const char* why) { m->tp_why = why; };
-  if (nb > TP_LPE - 1) return no("more than 31 bodies (lane 31 of an environment must stay empty)");
+  if (nb > LPE - 1)
+    return no(variant ? "more than 63 bodies (the last lane of an environment must stay empty)"
+                      : "more than 31 bodies (lane 31 of an environment must stay empty)");
   std::vector<int> depth(nb, 0), dd(nv, 1), jnt_of(nb, -1), act_of(nv, -1);
   for (int b = 1; b < nb; b++) {
     depth[b] = depth[s.body_parentid[b]] + 1;
@@ -102,15 +111,15 @@ static void build_tp(bs_model* m) {
     maxdd = dd[i] > maxdd ? dd[i] : maxdd;
   }
   if (maxdd > TP_MAXD) return no("dof tree deeper than TP_MAXD");
-  if (maxdepth > 32) return no("body tree too deep");
+  if (maxdepth > LPE) return no("body tree too deep");
   for (int u = 0; u < nu; u++) {
     if (act_of[s.actuator_trnid[u]] >= 0) return no("two actuators on one joint");
     act_of[s.actuator_trnid[u]] = u;
   }
   std::vector<int32_t>& T = m->tp_table;
-  T.assign((size_t)TPI_TOTAL * TP_LPE, -1);
-  auto at = [&](int f, int l) -> int32_t& { return T[(size_t)f * TP_LPE + l]; };
-  for (int l = 0; l < TP_LPE; l++) {
+  T.assign((size_t)TPI_TOTAL * LPE, -1);
+  auto at = [&](int f, int l) -> int32_t& { return T[(size_t)f * LPE + l]; };
+  for (int l = 0; l < LPE; l++) {
     at(TPI_PARENT, l) = l; at(TPI_DEPTH, l) = -1; at(TPI_DD, l) = 0; at(TPI_ROOT, l) = -1;
   }
   std::vector<int> nbc(nb, 0), ndc(nb, 0);
@@ -149,18 +158,18 @@ static void build_tp(bs_model* m) {
   m->tp.chain = maxdd >= 3;
   for (int j = 0; j < nv; j++)
     if (dd[j] >= 3 && s.dof_bodyid[s.dof_parentid[j]] != s.dof_bodyid[j] - 1) m->tp.chain = 0;
-  if (getenv("BS_NO_CHAIN")) m->tp.chain = 0;
+  if (getenv("BS_NO_CHAIN") || variant) m->tp.chain = 0;  // the wide build has no CHAIN instantiations
   // levels whose bodies all sit on the lane after their parent's
-  for (int L = 0; L < 34; L++) m->tp.lvl_next[L] = 0;
-  for (int L = 2; L <= maxdepth && L < 34; L++) {
+  for (int L = 0; L < TP_MAXLVL; L++) m->tp.lvl_next[L] = 0;
+  for (int L = 2; L <= maxdepth && L < TP_MAXLVL; L++) {
     bool all = true, any = false;
     for (int b = 1; b < nb; b++)
       if (depth[b] == L) { any = true; if (s.body_parentid[b] != b - 1) all = false; }
     m->tp.lvl_next[L] = any && all;
   }
   // levels whose bodies (two or more) all hang off one body
-  for (int L = 0; L < 34; L++) m->tp.lvl_parent[L] = -1;
-  for (int L = 2; L <= maxdepth && L < 34; L++) {
+  for (int L = 0; L < TP_MAXLVL; L++) m->tp.lvl_parent[L] = -1;
+  for (int L = 2; L <= maxdepth && L < TP_MAXLVL; L++) {
     int par = -1, cnt = 0;
     bool one = true;
     for (int b = 1; b < nb; b++)
@@ -172,8 +181,8 @@ static void build_tp(bs_model* m) {
     if (one && cnt >= 2 && par > 0) m->tp.lvl_parent[L] = par;
   }
   // equalities: owner = dof1's lane, other = dof2 (must be an ancestor dof of dof1)
-  for (size_t r = 0; r < m->eq_dof1.size(); r++) {
-    const int d1 = m->eq_dof1[r], d2 = m->eq_dof2[r];
+  for (size_t r = 0; r < mdl->eq_dof1.size(); r++) {
+    const int d1 = mdl->eq_dof1[r], d2 = mdl->eq_dof2[r];
     if (d2 < 0) return no("single-joint equality");
     const int b1 = s.dof_bodyid[d1], b2 = s.dof_bodyid[d2];
     int pos = -1, a = 1;
@@ -183,24 +192,25 @@ static void build_tp(bs_model* m) {
     if (at(TPI_EQ_OWN, b1) >= 0 || at(TPI_EQ_SRC, b2) >= 0) return no("a dof takes part in two equalities of the same role");
     at(TPI_EQ_OWN, b1) = (int)r; at(TPI_EQ_OTHER, b1) = b2; at(TPI_EQ_POS, b1) = pos; at(TPI_EQ_SRC, b2) = b1;
   }
-  const int neq = (int)m->eq_dof1.size(), nfric = (int)m->fric_dof.size();
-  for (int k = 0; k < nfric; k++) at(TPI_FRIC_ROW, s.dof_bodyid[m->fric_dof[k]]) = neq + k;
-  for (size_t k = 0; k < m->lim_jnt.size(); k++) at(TPI_LIM_ROW, s.jnt_bodyid[m->lim_jnt[k]]) = neq + nfric + 2 * (int)k;
-  for (int l = 0; l < TP_LPE; l++) at(TPI_ANCMASK, l) = 0;
+  const int neq = (int)mdl->eq_dof1.size(), nfric = (int)mdl->fric_dof.size();
+  for (int k = 0; k < nfric; k++) at(TPI_FRIC_ROW, s.dof_bodyid[mdl->fric_dof[k]]) = neq + k;
+  for (size_t k = 0; k < mdl->lim_jnt.size(); k++) at(TPI_LIM_ROW, s.jnt_bodyid[mdl->lim_jnt[k]]) = neq + nfric + 2 * (int)k;
+  for (int l = 0; l < LPE; l++) { at(TPI_ANCMASK, l) = 0; at(TPI_ANCMASK_HI, l) = 0; }
   for (int b = 1; b < nb; b++) {
-    uint32_t mask = 0;
+    uint64_t mask = 0;
     for (int a = b; a > 0; a = s.body_parentid[a])
-      if (jnt_of[a] >= 0) mask |= 1u << a;
-    at(TPI_ANCMASK, b) = (int32_t)mask;
+      if (jnt_of[a] >= 0) mask |= (uint64_t)1 << a;
+    at(TPI_ANCMASK, b) = (int32_t)(uint32_t)mask;
+    at(TPI_ANCMASK_HI, b) = (int32_t)(uint32_t)(mask >> 32);
   }
   // state-independent parts of the constraint rows, with the kernels' own functions
   std::vector<double>& Dt = m->tp_dtable;
-  Dt.assign((size_t)TPD_TOTAL * TP_LPE, 0.0);
-  auto dat = [&](int f, int l) -> double& { return Dt[(size_t)f * TP_LPE + l]; };
+  Dt.assign((size_t)TPD_TOTAL * LPE, 0.0);
+  auto dat = [&](int f, int l) -> double& { return Dt[(size_t)f * LPE + l]; };
   DevModel hm;
   memset(&hm, 0, sizeof hm);
   hm.disableflags = s.disableflags; hm.timestep = s.timestep;
-  for (int l = 0; l < TP_LPE; l++) dat(TPD_LIM_K, l) = -1.0;
+  for (int l = 0; l < LPE; l++) dat(TPD_LIM_K, l) = -1.0;
   for (int b = 1; b < nb; b++) {
     const int j = jnt_of[b];
     if (j < 0) continue;
@@ -230,15 +240,15 @@ static void build_tp(bs_model* m) {
     }
     const int r = at(TPI_EQ_OWN, b);
     if (r >= 0) {
-      kb_from_solref(hm, m->eq_solref.data() + 2 * r, m->eq_solimp.data() + 5 * r, K, B);
+      kb_from_solref(hm, mdl->eq_solref.data() + 2 * r, mdl->eq_solimp.data() + 5 * r, K, B);
       dat(TPD_EQ_K, b) = K; dat(TPD_EQ_B, b) = B;
-      dat(TPD_EQ_DIAG, b) = iw + s.dof_invweight0[m->eq_dof2[r]];
+      dat(TPD_EQ_DIAG, b) = iw + s.dof_invweight0[mdl->eq_dof2[r]];
     }
   }
   // the lane-major record of everything a lane reads per step (TPK_*)
   std::vector<double>& Kt = m->tp_ktable;
-  Kt.assign((size_t)TP_LPE * TPK_N, 0.0);
-  for (int l = 0; l < TP_LPE; l++) {
+  Kt.assign((size_t)LPE * TPK_N, 0.0);
+  for (int l = 0; l < LPE; l++) {
     double* r = &Kt[(size_t)l * TPK_N];
     const int b = l < nb ? l : 0;  // lanes beyond the bodies read body 0, lanes without a joint read joint 0 (as the kernels index)
     const int j = l < nb ? jnt_of[b] : -1;
@@ -254,14 +264,14 @@ static void build_tp(bs_model* m) {
     }
     const int e = at(TPI_EQ_OWN, l);
     if (e >= 0) {
-      for (int q = 0; q < 5; q++) { r[TPK_EQDATA + q] = m->eq_data[5 * e + q]; r[TPK_EQSOLIMP + q] = m->eq_solimp[5 * e + q]; }
-      r[TPK_EQQPOS0] = s.qpos0[m->eq_jnt2[e]];
+      for (int q = 0; q < 5; q++) { r[TPK_EQDATA + q] = mdl->eq_data[5 * e + q]; r[TPK_EQSOLIMP + q] = mdl->eq_solimp[5 * e + q]; }
+      r[TPK_EQQPOS0] = s.qpos0[mdl->eq_jnt2[e]];
     }
   }
   // PGS sweep order = efc order: equalities (owner lanes listed here), then frictionloss rows and limits in
   // dof order, which is the lane order (bodies and dofs are both numbered depth-first)
   m->tp_pgs.clear();
-  for (size_t r = 0; r < m->eq_dof1.size(); r++) m->tp_pgs.push_back(s.dof_bodyid[m->eq_dof1[r]]);
+  for (size_t r = 0; r < mdl->eq_dof1.size(); r++) m->tp_pgs.push_back(s.dof_bodyid[mdl->eq_dof1[r]]);
   m->tp.npgs = (int)m->tp_pgs.size();
   m->tp.maxdepth = maxdepth; m->tp.maxdd = maxdd; m->tp.nroots = nroots;
   int mind = maxdepth;
@@ -487,7 +497,8 @@ extern "C" int bs_model_create(const bs_model_desc* desc, bs_model** out) {
     for (int j = 0; j < nj; j++)
       if (m->d.jnt_limited[j]) m->lim_jnt.push_back(j);
   for (int i = 0; i < nv; i++) m->damped |= m->d.dof_damping[i] > 0;
-  build_tp(m);
+  build_tp(m, 0);
+  build_tp(m, 1);
   *out = m;
   return BS_OK;
 }
@@ -733,24 +744,33 @@ static int model_image(bs_model* m, int device, const DeviceImage** out) {
   PUT_CI(pair_nsub, nsub.data(), nsub.size());
 #undef PUT_CI
 #undef PUT_CD
-  TpModel tp = m->tp;
-  tp.lane = nullptr; tp.lane_d = nullptr; tp.lane_k = nullptr; tp.pgs_order = nullptr; tp.tri_pk = nullptr;
-  // row of the packed lower-triangle entry q = l + 32 t (k_tpc's dense Cholesky deals the entries round-robin)
-  std::vector<uint64_t> tri_pk(2 * TP_LPE, 0);
-  for (int l = 0; l < TP_LPE; l++)
+  TpModel tpd[2];
+  // row of the packed lower-triangle entry q = l + 32 t (k_tpc's dense Cholesky deals the entries round-robin);
+  // the wide build reads a byte per entry instead (33 chunks of 6 bits do not fit two words)
+  std::vector<uint64_t> tri_pk(2 * 32, 0);
+  for (int l = 0; l < 32; l++)
     for (int tt = 0; tt < TPC_NTRI; tt++) {
-      const int q = l + tt * TP_LPE;
+      const int q = l + tt * 32;
       int i = 0;
       while ((i + 1) * (i + 2) / 2 <= q) i++;
       if (tt < 12) tri_pk[l] |= (uint64_t)(i & 31) << (5 * tt);
-      else tri_pk[TP_LPE + l] |= (uint64_t)(i & 31) << (5 * (tt - 12));
+      else tri_pk[32 + l] |= (uint64_t)(i & 31) << (5 * (tt - 12));
     }
-  if (m->tp_ok) {
+  std::vector<uint8_t> tri_row(64 * 65 / 2 + 64, 0);
+  for (int i = 0, q = 0; i < 64; i++)
+    for (int k = 0; k <= i; k++) tri_row[q++] = (uint8_t)i;
+  for (int v = 0; v < 2; v++) {
+    const bs_model::TpHost& h = m->tpv[v];
+    TpModel& tp = tpd[v];
+    tp = h.tp;
+    tp.lane = nullptr; tp.lane_d = nullptr; tp.lane_k = nullptr; tp.pgs_order = nullptr; tp.tri_pk = nullptr; tp.tri_row = nullptr;
+    if (!h.tp_ok) continue;
     fix.push_back({pk.add(tri_pk.data(), tri_pk.size() * sizeof(uint64_t)), (void**)&tp.tri_pk});
-    fix.push_back({pk.add(m->tp_pgs.data(), m->tp_pgs.size() * sizeof(int32_t)), (void**)&tp.pgs_order});
-    fix.push_back({pk.add(m->tp_table.data(), m->tp_table.size() * sizeof(int32_t)), (void**)&tp.lane});
-    fix.push_back({pk.add(m->tp_dtable.data(), m->tp_dtable.size() * sizeof(double)), (void**)&tp.lane_d});
-    fix.push_back({pk.add(m->tp_ktable.data(), m->tp_ktable.size() * sizeof(double)), (void**)&tp.lane_k});
+    fix.push_back({pk.add(tri_row.data(), tri_row.size()), (void**)&tp.tri_row});
+    fix.push_back({pk.add(h.tp_pgs.data(), h.tp_pgs.size() * sizeof(int32_t)), (void**)&tp.pgs_order});
+    fix.push_back({pk.add(h.tp_table.data(), h.tp_table.size() * sizeof(int32_t)), (void**)&tp.lane});
+    fix.push_back({pk.add(h.tp_dtable.data(), h.tp_dtable.size() * sizeof(double)), (void**)&tp.lane_d});
+    fix.push_back({pk.add(h.tp_ktable.data(), h.tp_ktable.size() * sizeof(double)), (void**)&tp.lane_k});
   }
 #undef PUT_I
 #undef PUT_D
@@ -766,7 +786,7 @@ static int model_image(bs_model* m, int device, const DeviceImage** out) {
   }
   for (auto& f : fix) *f.slot = (char*)blob + f.off;
   DeviceImage im;
-  im.device = device; im.blob = blob; im.dm = dm; im.tp = tp; im.cm = cm;
+  im.device = device; im.blob = blob; im.dm = dm; im.tp[0] = tpd[0]; im.tp[1] = tpd[1]; im.cm = cm;
   m->images.push_back(im);
   *out = &m->images.back();
   return BS_OK;
@@ -783,6 +803,7 @@ struct bs_sim {
   bs_model* model = nullptr;
   DevModel dm;
   TpModel tp;
+  int wide = 0, lpe = 32;  // which tree-parallel build runs this sim: 32 lanes per environment, or the wide one (64)
   bool use_tp = false;
   bool narrow_ws = false, narrow_blocks = false;
   int nl_grid = 2048;  // wavefronts of the persistent narrowphase (k_c_narrow_list): one resident set at two per SIMD
@@ -798,7 +819,7 @@ struct bs_sim {
   long n_envs = 0, E = 0;
   hipStream_t own_stream = nullptr, stream = nullptr;
   void* arena = nullptr;
-  size_t arena_bytes = 0;
+  size_t arena_bytes = 0, carena_bytes = 0, gframe_bytes = 0, sarena_bytes = 0;
   FieldInfo fields[BS_F_COUNT];
   double* derived = nullptr;  // scratch for on-demand fields (xmat, geom_xpos, geom_xmat)
   size_t derived_rows = 0;
@@ -841,10 +862,12 @@ static int ensure_serial_contact(bs_sim* s) {
   const size_t rows = nr * nv + nr * 5 + nh + (pgs ? nr * nv : 0);
   const hipError_t he = hipMalloc(&s->sarena, rows * E * sizeof(double));
   if (he != hipSuccess) {
+    (void)hipGetLastError();  // a failed allocation leaves its error behind: the next call must not trip over it
     s->sarena = nullptr;
-    return fail(BS_ERR_NOMEM, "hipMalloc of %zu bytes for the serial contact solver failed: %s", rows * E * sizeof(double),
-                hipGetErrorString(he));
+    return fail(BS_ERR_NOMEM, "serial contact solver arena (Jacobian rows + dense Hessian, %zu bytes per environment): hipMalloc of %zu bytes for %ld environments failed: %s",
+                rows * sizeof(double), rows * E * sizeof(double), s->n_envs, hipGetErrorString(he));
   }
+  s->sarena_bytes = rows * E * sizeof(double);
   HIPCHK(hipMemsetAsync(s->sarena, 0, rows * E * sizeof(double), s->stream));
   double* dp = (double*)s->sarena;
   auto take = [&](size_t rows_) { double* q = dp; dp += rows_ * E; return q; };
@@ -863,8 +886,11 @@ static int ensure_serial_contact(bs_sim* s) {
 static inline dim3 grid_for(const bs_sim* s) { return dim3((unsigned)((s->n_envs + BS_BLOCK - 1) / BS_BLOCK)); }
 // tree-parallel kernels: one wavefront per pair of environments, the grid rounded up to whole rounds of the 8 XCDs
 // (physics_tp.h::tp_block deals each XCD a contiguous run of pairs)
-static inline dim3 grid_tp_n(long n_envs) { return dim3((unsigned)(((n_envs + 1) / 2 + 7) / 8 * 8)); }
-static inline dim3 grid_tp(const bs_sim* s) { return grid_tp_n(s->n_envs); }
+static inline dim3 grid_tp_n(long n_envs, int lpe) {
+  const long per = 64 / lpe;  // environments per wavefront
+  return dim3((unsigned)(((n_envs + per - 1) / per + 7) / 8 * 8));
+}
+static inline dim3 grid_tp(const bs_sim* s) { return grid_tp_n(s->n_envs, s->lpe); }
 // narrowphase: flattened work items by default; BS_NARROW=ws selects the work-stealing variant
 // (measured slower on MI355X at 65536 envs: 2.6 ms vs 1.9 ms)
 static void launch_narrow(bs_sim* s, const DevData& dd, hipStream_t st) {
@@ -882,9 +908,10 @@ static void launch_tpc_pass(bs_sim* s, const DevData& dd, hipStream_t st, int mo
   extern void bs_set_colcut(int);
   if (const char* e = getenv("BS_COLCUT")) bs_set_colcut(atoi(e));
 #endif
-  const dim3 g = grid_tp_n(dd.n_envs - dd.env0);
-  const size_t lds_col = (size_t)2 * s->cm.ngeom * TPG_SLOT * sizeof(double) + (size_t)2 * s->cm.npair * sizeof(int);  // frames, pair lists
-  bs_launch_tp_col(g, lds_col, st, s->dm, s->tp, dd, s->cm, s->cd);
+  const dim3 g = grid_tp_n(dd.n_envs - dd.env0, s->lpe);
+  const size_t nw = (size_t)(64 / s->lpe);  // environments per wavefront
+  const size_t lds_col = nw * s->cm.ngeom * TPG_SLOT * sizeof(double) + nw * s->cm.npair * sizeof(int);  // frames, pair lists
+  (s->wide ? bs_launch_tp_col_w : bs_launch_tp_col)(g, lds_col, st, s->dm, s->tp, dd, s->cm, s->cd);
   if (s->narrow_ws || s->narrow_blocks) {
     launch_narrow(s, dd, st);
   } else {
@@ -894,13 +921,16 @@ static void launch_tpc_pass(bs_sim* s, const DevData& dd, hipStream_t st, int mo
     bs_launch_narrow_list(dim3((unsigned)nb), st, s->cm, dd, s->cd, s->cm.has_prim);
   }
   const int ntri = s->dm.nbody * (s->dm.nbody + 1) / 2;
+  // LDS per wavefront: 64 contact slots and U rows whatever the build (2 x 32 or 1 x 64 lanes), Hessians / M^-1 per environment
   if (s->dm.solver == 0) {
-    const size_t lds = (size_t)(2 * TP_LPE * TPC_SLOT_PGS + 2 * TP_LPE * 3 + 2 * s->dm.nbody * tp_minv_stride(s->dm.nbody)) * sizeof(double);
-    bs_launch_tpc_pgs(g, lds, st, s->dm, s->tp, dd, s->cm, s->cd, mode, dump);
+    const size_t lds = (size_t)(64 * tpc_slot_pgs(s->lpe) + 64 * 3 + nw * s->dm.nbody * tp_minv_stride(s->dm.nbody)) * sizeof(double);
+    auto* launch = s->wide ? (full ? bs_launch_tpc_full_pgs_w : bs_launch_tpc_pgs_w) : (full ? bs_launch_tpc_full_pgs : bs_launch_tpc_pgs);
+    launch(g, lds, st, s->dm, s->tp, dd, s->cm, s->cd, mode, dump);
     return;
   }
-  const size_t lds = (size_t)(2 * ntri + 2 * TP_LPE * TPC_SLOT + 2 * TP_LPE * 3) * sizeof(double);
+  const size_t lds = (size_t)(nw * ntri + 64 * tpc_slot(s->lpe) + 64 * 3) * sizeof(double);
   auto* launch = s->dm.solver == 1 ? (full ? bs_launch_tpc_full_cg : bs_launch_tpc_cg) : (full ? bs_launch_tpc_full : (s->tp.chain ? bs_launch_tpc_chain : bs_launch_tpc));
+  if (s->wide) launch = s->dm.solver == 1 ? (full ? bs_launch_tpc_full_cg_w : bs_launch_tpc_cg_w) : (full ? bs_launch_tpc_full_w : bs_launch_tpc_w);
   launch(g, lds, st, s->dm, s->tp, dd, s->cm, s->cd, mode, dump);
 }
 // check: mj_checkPos/Vel first; integrate: mj_step (Euler) rather than mj_forward; fast: let the
@@ -971,11 +1001,14 @@ static void launch_step(bs_sim* s, int n_steps) {
     auto* launch = s->dm.solver == 0 ? (rk ? bs_launch_tp_rk4_pgs : bs_launch_tp_pgs)
                    : s->dm.solver == 1 ? (rk ? bs_launch_tp_rk4_cg : bs_launch_tp_cg)
                                        : (rk ? bs_launch_tp_rk4 : (s->tp.chain ? bs_launch_tp_chain : bs_launch_tp));
+    if (s->wide)
+      launch = s->dm.solver == 0 ? (rk ? bs_launch_tp_rk4_pgs_w : bs_launch_tp_pgs_w)
+               : s->dm.solver == 1 ? (rk ? bs_launch_tp_rk4_cg_w : bs_launch_tp_cg_w) : (rk ? bs_launch_tp_rk4_w : bs_launch_tp_w);
     int dump = 1;
 #ifdef TPC_CUTS
     if (const char* e = getenv("BS_CUT")) dump |= (atoi(e) + 1) << 8;
 #endif
-    launch(grid_tp(s), s->dm.solver == 0 ? (size_t)2 * s->dm.nbody * tp_minv_stride(s->dm.nbody) * sizeof(double) : 0, s->stream,
+    launch(grid_tp(s), s->dm.solver == 0 ? (size_t)(64 / s->lpe) * s->dm.nbody * tp_minv_stride(s->dm.nbody) * sizeof(double) : 0, s->stream,
            s->dm, s->tp, s->dd, n_steps, 0, dump);
   } else {
     bs_launch_step(grid_for(s), s->stream, s->dm, s->dd, n_steps);
@@ -1008,7 +1041,12 @@ extern "C" int bs_sim_create(const bs_model* const* models, int n_models, const 
       if (i == start) continue;  // no environment uses this model
       bs_sim* child = nullptr;
       tl_part_of_mixed = 1;  // the parts already step concurrently on three streams: a part keeps the old split threshold
-      const int rc = bs_sim_create(models + k, 1, nullptr, i - start, device, opt, &child);
+      bs_options po;
+      memset(&po, 0, sizeof po);
+      if (opt) po = *opt;
+      if (opt && opt->max_contacts_per_model && opt->max_contacts_per_model[k] > 0) po.max_contacts_per_env = opt->max_contacts_per_model[k];
+      po.max_contacts_per_model = nullptr;
+      const int rc = bs_sim_create(models + k, 1, nullptr, i - start, device, &po, &child);
       tl_part_of_mixed = 0;
       if (rc) { bs_sim_destroy(top); return rc; }
       top->parts.push_back(child);
@@ -1049,7 +1087,7 @@ extern "C" int bs_sim_create(const bs_model* const* models, int n_models, const 
   if (rc) return rc;
 
   bs_sim* s = new bs_sim();
-  s->model = model; s->dm = img->dm; s->tp = img->tp; s->device = device; s->n_envs = n_envs;
+  s->model = model; s->dm = img->dm; s->device = device; s->n_envs = n_envs;
   // every failure below goes through bs_sim_destroy, which tolerates a partially built sim
 #define HIPCHK_S(call)                                                                              \
   do {                                                                                              \
@@ -1076,8 +1114,19 @@ extern "C" int bs_sim_create(const bs_model* const* models, int n_models, const 
   // every solver with either integrator, with and without contacts (PGS with contacts: Euler)
   const bool serial = kv && strcmp(kv, "serial") == 0;
   const bool tp_solver = true;  // Newton, CG and PGS all have tree-parallel contact kernels
-  s->use_tp = !contacts && model->tp_ok && !serial;
-  s->use_tpc = contacts && tp_solver && model->tp_ok && s->cm.maxcon <= TP_LPE && !serial;
+  // which tree-parallel build: the 32-lane kernels when the model fits them and (with contacts) at most 32 contacts per
+  // environment are asked for; else the wide ones (nbody <= 63, up to 64 contacts; BS_KERNEL=wide forces them); else serial
+  {
+    const bool force_wide = kv && strcmp(kv, "wide") == 0;
+    const bool fits32 = model->tpv[0].tp_ok && (!contacts || s->cm.maxcon <= 32) && !force_wide;
+    const bool fits64 = model->tpv[1].tp_ok && (!contacts || s->cm.maxcon <= 64);
+    s->wide = !fits32 && fits64;
+    s->lpe = s->wide ? 64 : 32;
+    s->tp = img->tp[s->wide];
+    const bool ok = fits32 || fits64;
+    s->use_tp = !contacts && ok && !serial;
+    s->use_tpc = contacts && tp_solver && ok && !serial;
+  }
   {
     const char* nk = getenv("BS_NARROW");
     s->narrow_ws = nk && strcmp(nk, "ws") == 0 && !s->cm.has_prim;  // the work-stealing variant knows hulls and planes only
@@ -1087,9 +1136,10 @@ extern "C" int bs_sim_create(const bs_model* const* models, int n_models, const 
     const char* gr = getenv("BS_NL_GRID");
     if (gr && atoi(gr) > 0) s->nl_grid = atoi(gr);
   }
-  if (kv && strcmp(kv, "tp") == 0 && !model->tp_ok) {
+  if (kv && (strcmp(kv, "tp") == 0 || strcmp(kv, "wide") == 0) && !(contacts ? s->use_tpc : s->use_tp)) {
+    const std::string why = model->tpv[1].tp_ok ? "more contacts per environment requested than a lane group holds" : model->tpv[1].tp_why;
     delete s;
-    return fail(BS_ERR_UNSUPPORTED, "BS_KERNEL=tp but the model is not eligible: %s", model->tp_why.c_str());
+    return fail(BS_ERR_UNSUPPORTED, "BS_KERNEL=%s but the model is not eligible: %s", kv, why.c_str());
   }
   s->E = (n_envs + 63) / 64 * 64;
   const DevModel& m = s->dm;
@@ -1131,10 +1181,12 @@ extern "C" int bs_sim_create(const bs_model* const* models, int n_models, const 
   s->arena_bytes = dbl_bytes + int_bytes + (size_t)E;  // + the device copy of bs_reset's mask
   hipError_t he = hipMalloc(&s->arena, s->arena_bytes);
   if (he != hipSuccess) {
+    (void)hipGetLastError();  // a failed allocation leaves its error behind: the next call must not trip over it
     const size_t want = s->arena_bytes;
     s->arena = nullptr;
     bs_sim_destroy(s);
-    return fail(BS_ERR_NOMEM, "bs_sim_create: hipMalloc of %zu bytes failed: %s", want, hipGetErrorString(he));
+    return fail(BS_ERR_NOMEM, "bs_sim_create: state arena (every [rows][E] field, %zu bytes per environment): hipMalloc of %zu bytes for %lld environments failed: %s",
+                want / (size_t)E, want, (long long)n_envs, hipGetErrorString(he));
   }
   HIPCHK_S(hipMemset(s->arena, 0, s->arena_bytes));
   double* base = (double*)s->arena;
@@ -1171,11 +1223,13 @@ extern "C" int bs_sim_create(const bs_model* const* models, int n_models, const 
     const size_t bytes = drows * E * sizeof(double) + irows * E * sizeof(int) + 16 + nstat * 8 + nitems * sizeof(int);
     he = hipMalloc(&s->carena, bytes);
     if (he != hipSuccess) {
+    (void)hipGetLastError();  // a failed allocation leaves its error behind: the next call must not trip over it
       s->carena = nullptr;
       bs_sim_destroy(s);
-      return fail(BS_ERR_NOMEM, "bs_sim_create: hipMalloc of %zu bytes for the contact arena failed: %s", bytes,
-                  hipGetErrorString(he));
+      return fail(BS_ERR_NOMEM, "bs_sim_create: contact arena (candidate + contact lists + narrowphase work list, %zu bytes per environment): hipMalloc of %zu bytes for %lld environments failed: %s",
+                  bytes / (size_t)E, bytes, (long long)n_envs, hipGetErrorString(he));
     }
+    s->carena_bytes = bytes;
     HIPCHK_S(hipMemset(s->carena, 0, bytes));
     double* dp = (double*)s->carena;
     auto take = [&](size_t rows_) { double* q = dp; dp += rows_ * (size_t)E; return q; };
@@ -1200,11 +1254,13 @@ extern "C" int bs_sim_create(const bs_model* const* models, int n_models, const 
       const size_t gbytes = (size_t)E * s->cm.ngeom * 12 * sizeof(double);
       he = hipMalloc(&s->gframe, gbytes);
       if (he != hipSuccess) {
+    (void)hipGetLastError();  // a failed allocation leaves its error behind: the next call must not trip over it
         s->gframe = nullptr;
         bs_sim_destroy(s);
-        return fail(BS_ERR_NOMEM, "bs_sim_create: hipMalloc of %zu bytes for the geom frame records failed: %s", gbytes,
-                    hipGetErrorString(he));
+        return fail(BS_ERR_NOMEM, "bs_sim_create: geom-frame records (%zu bytes per environment): hipMalloc of %zu bytes for %lld environments failed: %s",
+                    gbytes / (size_t)E, gbytes, (long long)n_envs, hipGetErrorString(he));
       }
+      s->gframe_bytes = gbytes;
       HIPCHK_S(hipMemset(s->gframe, 0, gbytes));
       c.gframe = (double*)s->gframe;
       // candidates as 64-byte records in the memory of the five [row][E] candidate arrays (the same size: 7 doubles + 2 ints per slot)
@@ -1267,24 +1323,43 @@ extern "C" int bs_sim_kernel_path(const bs_sim* s, char* buf, int cap) {
   const char* kv = getenv("BS_KERNEL");
   std::string why;
   if (!tp) {
-    if (!s->model->tp_ok) why = s->model->tp_why;
-    else if (kv && strcmp(kv, "serial") == 0) why = "BS_KERNEL=serial";
-    else if (s->contacts && s->cm.maxcon > TP_LPE) why = "more than 32 contacts per environment requested";
+    if (kv && strcmp(kv, "serial") == 0) why = "BS_KERNEL=serial";
+    else if (!s->model->tpv[1].tp_ok) why = s->model->tpv[1].tp_why;  // the wide build's reason: it admits everything the 32-lane one does
+    else if (s->contacts && s->cm.maxcon > 64) why = "more than 64 contacts per environment requested";
     else why = "not selected";
   }
   std::string fastname;
   {
     const char* sol = s->dm.solver == 0 ? "_pgs" : s->dm.solver == 1 ? "_cg" : "";
     const bool chain = s->tp.chain && s->dm.solver == 2;
+    const char* w = s->wide ? "_w" : "";  // the wide build: 64 lanes per environment
     if (s->contacts)
-      fastname = std::string("tree-parallel (k_tp_col, k_c_narrow_list, k_tpc") + (chain ? "_chain" : sol) + ")";
+      fastname = std::string("tree-parallel (k_tp_col") + w + ", k_c_narrow_list, k_tpc" + (chain ? "_chain" : sol) + w + ")";
     else
-      fastname = std::string("tree-parallel (k_tp") + (chain && s->dm.integrator == 0 ? "_chain" : (std::string(s->dm.integrator == 1 ? "_rk4" : "") + sol).c_str()) + ")";
+      fastname = std::string("tree-parallel (k_tp") + (chain && s->dm.integrator == 0 ? "_chain" : (std::string(s->dm.integrator == 1 ? "_rk4" : "") + sol).c_str()) + w + ")";
   }
   snprintf(buf, (size_t)cap, "%s%s", tp ? fastname.c_str()
                                        : (s->contacts ? "serial (k_c_pos, k_c_broad, k_c_narrow_flat, k_c_dyn): " : "serial (k_step): "),
            why.c_str());
   return tp ? 1 : 0;
+}
+
+// device memory held by the sim, per arena (a mixed-model sim sums its parts)
+extern "C" int bs_sim_footprint(const bs_sim* s, int64_t out[5]) {
+  if (!s || !out) return fail(BS_ERR_INVALID, "bs_sim_footprint: null argument");
+  for (int q = 0; q < 5; q++) out[q] = 0;
+  if (!s->parts.empty()) {
+    for (const bs_sim* c : s->parts) {
+      int64_t t[5];
+      const int rc = bs_sim_footprint(c, t);
+      if (rc) return rc;
+      for (int q = 0; q < 5; q++) out[q] += t[q];
+    }
+    return BS_OK;
+  }
+  out[0] = (int64_t)s->arena_bytes; out[1] = (int64_t)s->carena_bytes; out[2] = (int64_t)s->gframe_bytes;
+  out[3] = (int64_t)s->sarena_bytes; out[4] = (int64_t)s->E;
+  return BS_OK;
 }
 
 extern "C" int bs_sim_destroy(bs_sim* s) {
@@ -1381,17 +1456,18 @@ extern "C" int bs_forward(bs_sim* s) {
     }
     return BS_OK;
   }
-  if (s->contacts && s->use_tpc && s->dm.solver != 0) {
-    // every intermediate written by the tree-parallel kernels too (k_tpc_full / k_tpc_full_cg, round 2): no
+  if (s->contacts && s->use_tpc) {
+    // every intermediate written by the tree-parallel kernels too (k_tpc_full / _cg, round 2; _pgs, round 3): no
     // serial pipeline, none of its 43 KB per environment of solver buffers
     launch_tpc_pass(s, s->dd, s->stream, 1, 2, true);
   } else if (s->contacts) {
-    const int rc = ensure_serial_contact(s);  // PGS with contacts, ineligible models: serial pipeline
+    const int rc = ensure_serial_contact(s);  // ineligible models: serial pipeline
     if (rc) return rc;
     launch_contact_pass(s, 0, 0);
   } else if (s->use_tp) {
     auto* launch = s->dm.solver == 0 ? bs_launch_tp_full_pgs : s->dm.solver == 1 ? bs_launch_tp_full_cg : bs_launch_tp_full;
-    launch(grid_tp(s), s->dm.solver == 0 ? (size_t)2 * s->dm.nbody * tp_minv_stride(s->dm.nbody) * sizeof(double) : 0, s->stream,
+    if (s->wide) launch = s->dm.solver == 0 ? bs_launch_tp_full_pgs_w : s->dm.solver == 1 ? bs_launch_tp_full_cg_w : bs_launch_tp_full_w;
+    launch(grid_tp(s), s->dm.solver == 0 ? (size_t)(64 / s->lpe) * s->dm.nbody * tp_minv_stride(s->dm.nbody) * sizeof(double) : 0, s->stream,
            s->dm, s->tp, s->dd, 1, 1, 2);
   } else
     bs_launch_forward(grid_for(s), s->stream, s->dm, s->dd);

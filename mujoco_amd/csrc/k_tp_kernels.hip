@@ -3,13 +3,21 @@
 // instantiations (each a few thousand lines of straight-line fp64 code) build in parallel.
 // Block = one 64-lane wavefront = two environments; __launch_bounds__(64, 2) = two waves per SIMD.
 #include "kernels.h"
+// kernel and launcher names: k_<name> / bs_launch_<name>, with the suffix _w in the wide build (-DTP_LPE=64)
+#if TP_LPE == 64
+#define KN(name) k_##name##_w
+#define LN(name) bs_launch_##name##_w
+#else
+#define KN(name) k_##name
+#define LN(name) bs_launch_##name
+#endif
 #ifndef TP_OCC
 #define TP_OCC 2
 #endif
 
 #define TP_KERNEL(name, CONTACTS_, FULL_, RK4_, CG_, PGS_, PARK_, MINV_) TP_KERNEL_C(name, CONTACTS_, FULL_, RK4_, CG_, PGS_, PARK_, MINV_, false)
 #define TP_KERNEL_C(name, CONTACTS_, FULL_, RK4_, CG_, PGS_, PARK_, MINV_, CHAIN_)                                   \
-  __global__ __launch_bounds__(64, TP_OCC) void k_##name(DevModel m, TpModel t, DevData d, int nsteps, int mode, int dump) { \
+  __global__ __launch_bounds__(64, TP_OCC) void KN(name)(DevModel m, TpModel t, DevData d, int nsteps, int mode, int dump) { \
     __shared__ int tbl[TPL_TOTAL * 64];                                                                               \
     __shared__ double park[PARK_ ? (TP_MAXD + 1) * 64 : 1];                                                           \
     extern __shared__ double minv[]; /* PGS: 2 x nbody x tp_minv_stride(nbody) */                                     \
@@ -18,48 +26,48 @@
     ColData cd;                                                                                                       \
     tp_run<CONTACTS_, FULL_, RK4_, CG_, PGS_, CHAIN_>(m, t, d, nsteps, mode, dump, sh, cm, cd);                       \
   }                                                                                                                   \
-  void bs_launch_##name(BS_TP_ARGS) { hipLaunchKernelGGL(k_##name, g, dim3(64), lds, st, m, t, d, nsteps, mode, dump); }
+  void LN(name)(BS_TP_ARGS) { hipLaunchKernelGGL(KN(name), g, dim3(64), lds, st, m, t, d, nsteps, mode, dump); }
 
 // both instantiations in one kernel, chosen by TpModel::chain (uniform): for the variants that are not worth an
 // object file of their own per instantiation
 #define TP_KERNEL_D(name, CONTACTS_, FULL_, RK4_, CG_, PGS_, PARK_, MINV_)                                           \
-  __global__ __launch_bounds__(64, TP_OCC) void k_##name(DevModel m, TpModel t, DevData d, int nsteps, int mode, int dump) { \
+  __global__ __launch_bounds__(64, TP_OCC) void KN(name)(DevModel m, TpModel t, DevData d, int nsteps, int mode, int dump) { \
     __shared__ int tbl[TPL_TOTAL * 64];                                                                               \
     __shared__ double park[PARK_ ? (TP_MAXD + 1) * 64 : 1];                                                           \
     extern __shared__ double minv[];                                                                                  \
     const TpShared sh = {tbl, nullptr, nullptr, nullptr, PARK_ ? park : nullptr, MINV_ ? minv : nullptr};             \
     ColModel cm;                                                                                                      \
     ColData cd;                                                                                                       \
-    if (t.chain) tp_run<CONTACTS_, FULL_, RK4_, CG_, PGS_, true>(m, t, d, nsteps, mode, dump, sh, cm, cd);            \
+    if (TP_LPE != 64 && t.chain) tp_run<CONTACTS_, FULL_, RK4_, CG_, PGS_, TP_LPE != 64>(m, t, d, nsteps, mode, dump, sh, cm, cd); \
     else tp_run<CONTACTS_, FULL_, RK4_, CG_, PGS_, false>(m, t, d, nsteps, mode, dump, sh, cm, cd);                   \
   }                                                                                                                   \
-  void bs_launch_##name(BS_TP_ARGS) { hipLaunchKernelGGL(k_##name, g, dim3(64), lds, st, m, t, d, nsteps, mode, dump); }
+  void LN(name)(BS_TP_ARGS) { hipLaunchKernelGGL(KN(name), g, dim3(64), lds, st, m, t, d, nsteps, mode, dump); }
 #define TPC_KERNEL_D(name, CG_, PGS_)                                                                                  \
-  __global__ __launch_bounds__(64, TPC_OCC) void k_##name(DevModel m, TpModel t, DevData d, ColModel cm, ColData cd,  \
+  __global__ __launch_bounds__(64, TPC_OCC) void KN(name)(DevModel m, TpModel t, DevData d, ColModel cm, ColData cd,  \
                                                           int mode, int dump) {                                      \
     __shared__ int tbl[TPL_TOTAL * 64];                                                                               \
     extern __shared__ double tpc_dyn[];                                                                               \
     const int ntri = m.nbody * (m.nbody + 1) / 2;                                                                     \
-    const TpShared sh = {tbl, tpc_dyn, tpc_dyn + 2 * ntri, tpc_dyn + 2 * ntri + 2 * TP_LPE * TPC_SLOT, nullptr, nullptr}; \
-    if (t.chain) tp_run<true, false, false, CG_, PGS_, true>(m, t, d, 1, mode, dump, sh, cm, cd);                     \
+    const TpShared sh = {tbl, tpc_dyn, tpc_dyn + TP_ENVS * ntri, tpc_dyn + TP_ENVS * ntri + 64 * TPC_SLOT, nullptr, nullptr}; \
+    if (TP_LPE != 64 && t.chain) tp_run<true, false, false, CG_, PGS_, TP_LPE != 64>(m, t, d, 1, mode, dump, sh, cm, cd); \
     else tp_run<true, false, false, CG_, PGS_, false>(m, t, d, 1, mode, dump, sh, cm, cd);                            \
   }                                                                                                                   \
-  void bs_launch_##name(BS_TPC_ARGS) { hipLaunchKernelGGL(k_##name, g, dim3(64), lds, st, m, t, d, cm, cd, mode, dump); }
+  void LN(name)(BS_TPC_ARGS) { hipLaunchKernelGGL(KN(name), g, dim3(64), lds, st, m, t, d, cm, cd, mode, dump); }
 
 // contacts: candidates from k_tp_col + the narrowphase kernel, one step per launch.  Dynamic LDS:
 // packed Hessians for nbody rows (2 envs), then contact slots, then the U staging rows
 #define TPC_KERNEL(name, CG_, PGS_) TPC_KERNEL_F(name, false, CG_, PGS_)
 #define TPC_KERNEL_F(name, FULL_, CG_, PGS_) TPC_KERNEL_FC(name, FULL_, CG_, PGS_, false)
 #define TPC_KERNEL_FC(name, FULL_, CG_, PGS_, CHAIN_)                                                                  \
-  __global__ __launch_bounds__(64, TPC_OCC) void k_##name(DevModel m, TpModel t, DevData d, ColModel cm, ColData cd,  \
+  __global__ __launch_bounds__(64, TPC_OCC) void KN(name)(DevModel m, TpModel t, DevData d, ColModel cm, ColData cd,  \
                                                           int mode, int dump) {                                      \
     __shared__ int tbl[TPL_TOTAL * 64];                                                                               \
     extern __shared__ double tpc_dyn[];                                                                               \
     const int ntri = m.nbody * (m.nbody + 1) / 2;                                                                     \
-    const TpShared sh = {tbl, tpc_dyn, tpc_dyn + 2 * ntri, tpc_dyn + 2 * ntri + 2 * TP_LPE * TPC_SLOT, nullptr, nullptr}; \
+    const TpShared sh = {tbl, tpc_dyn, tpc_dyn + TP_ENVS * ntri, tpc_dyn + TP_ENVS * ntri + 64 * TPC_SLOT, nullptr, nullptr}; \
     tp_run<true, FULL_, false, CG_, PGS_, CHAIN_>(m, t, d, 1, mode, dump, sh, cm, cd);                                \
   }                                                                                                                   \
-  void bs_launch_##name(BS_TPC_ARGS) { hipLaunchKernelGGL(k_##name, g, dim3(64), lds, st, m, t, d, cm, cd, mode, dump); }
+  void LN(name)(BS_TPC_ARGS) { hipLaunchKernelGGL(KN(name), g, dim3(64), lds, st, m, t, d, cm, cd, mode, dump); }
 
 #if defined(TPK_tp)
 TP_KERNEL(tp, false, false, false, false, false, true, false)
@@ -88,22 +96,22 @@ TP_KERNEL(tp_full_pgs, false, true, false, false, true, false, true)
 #ifdef TPC_CUTS  // developer build: the kernel returns at section BS_COLCUT
 static int g_colcut = -1;
 void bs_set_colcut(int c) { g_colcut = c; }
-__global__ __launch_bounds__(64) void k_tp_col(DevModel m, TpModel t, DevData d, ColModel cm, ColData cd, int colcut) {
+__global__ __launch_bounds__(64) void KN(tp_col)(DevModel m, TpModel t, DevData d, ColModel cm, ColData cd, int colcut) {
   extern __shared__ double tpg_dyn[];
   tp_collide_prep(m, t, d, cm, cd, tpg_dyn, colcut);
 }
-void bs_launch_tp_col(dim3 g, size_t lds, hipStream_t st, const DevModel& m, const TpModel& t, const DevData& d,
+void LN(tp_col)(dim3 g, size_t lds, hipStream_t st, const DevModel& m, const TpModel& t, const DevData& d,
                       const ColModel& cm, const ColData& cd) {
-  hipLaunchKernelGGL(k_tp_col, g, dim3(64), lds, st, m, t, d, cm, cd, g_colcut);
+  hipLaunchKernelGGL(KN(tp_col), g, dim3(64), lds, st, m, t, d, cm, cd, g_colcut);
 }
 #else
-__global__ __launch_bounds__(64) void k_tp_col(DevModel m, TpModel t, DevData d, ColModel cm, ColData cd) {
+__global__ __launch_bounds__(64) void KN(tp_col)(DevModel m, TpModel t, DevData d, ColModel cm, ColData cd) {
   extern __shared__ double tpg_dyn[];  // geom frames of the two environments
   tp_collide_prep(m, t, d, cm, cd, tpg_dyn);
 }
-void bs_launch_tp_col(dim3 g, size_t lds, hipStream_t st, const DevModel& m, const TpModel& t, const DevData& d,
+void LN(tp_col)(dim3 g, size_t lds, hipStream_t st, const DevModel& m, const TpModel& t, const DevData& d,
                       const ColModel& cm, const ColData& cd) {
-  hipLaunchKernelGGL(k_tp_col, g, dim3(64), lds, st, m, t, d, cm, cd);
+  hipLaunchKernelGGL(KN(tp_col), g, dim3(64), lds, st, m, t, d, cm, cd);
 }
 #endif
 #elif defined(TPK_tpc)
@@ -117,20 +125,27 @@ TPC_KERNEL_D(tpc_cg, true, false)
 TPC_KERNEL_F(tpc_full, true, false, false)
 #elif defined(TPK_tpc_full_cg)
 TPC_KERNEL_F(tpc_full_cg, true, true, false)
-#elif defined(TPK_tpc_pgs)
+#elif defined(TPK_tpc_pgs) || defined(TPK_tpc_full_pgs)
 // contacts, PGS: no Hessian; dynamic LDS = contact slots (wider: aref, forces, B per contact), the U staging rows,
-// then M^-1 of the two environments
-__global__ __launch_bounds__(64, TPC_OCC) void k_tpc_pgs(DevModel m, TpModel t, DevData d, ColModel cm, ColData cd, int mode,
-                                                   int dump) {
-  __shared__ int tbl[TPL_TOTAL * 64];
-  extern __shared__ double tpc_dyn[];
-  double* cg = tpc_dyn;
-  double* U = cg + 2 * TP_LPE * TPC_SLOT_PGS;
-  double* minv = U + 2 * TP_LPE * 3;
-  const TpShared sh = {tbl, nullptr, cg, U, nullptr, minv};
-  tp_run<true, false, false, false, true>(m, t, d, 1, mode, dump, sh, cm, cd);
-}
-void bs_launch_tpc_pgs(BS_TPC_ARGS) { hipLaunchKernelGGL(k_tpc_pgs, g, dim3(64), lds, st, m, t, d, cm, cd, mode, dump); }
+// then M^-1 of the two environments.  k_tpc_full_pgs = bs_forward (every intermediate written), so that no eligible
+// configuration needs the serial pipeline and its 43 KB per environment of solver buffers
+#define TPC_PGS_KERNEL(name, FULL_)                                                                                   \
+  __global__ __launch_bounds__(64, TPC_OCC) void KN(name)(DevModel m, TpModel t, DevData d, ColModel cm, ColData cd,  \
+                                                          int mode, int dump) {                                      \
+    __shared__ int tbl[TPL_TOTAL * 64];                                                                               \
+    extern __shared__ double tpc_dyn[];                                                                               \
+    double* cg = tpc_dyn;                                                                                             \
+    double* U = cg + 64 * TPC_SLOT_PGS;                                                                               \
+    double* minv = U + 64 * 3;                                                                                        \
+    const TpShared sh = {tbl, nullptr, cg, U, nullptr, minv};                                                         \
+    tp_run<true, FULL_, false, false, true>(m, t, d, 1, mode, dump, sh, cm, cd);                                      \
+  }                                                                                                                   \
+  void LN(name)(BS_TPC_ARGS) { hipLaunchKernelGGL(KN(name), g, dim3(64), lds, st, m, t, d, cm, cd, mode, dump); }
+#ifdef TPK_tpc_pgs
+TPC_PGS_KERNEL(tpc_pgs, false)
+#else
+TPC_PGS_KERNEL(tpc_full_pgs, true)
+#endif
 #else
 #error "compile with -DTPK_<kernel name> (see the Makefile)"
 #endif

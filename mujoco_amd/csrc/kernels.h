@@ -73,3 +73,23 @@ void bs_launch_tpc_cg(BS_TPC_ARGS);     // contacts, CG
 void bs_launch_tpc_pgs(BS_TPC_ARGS);    // contacts, PGS
 void bs_launch_tpc_full(BS_TPC_ARGS);     // bs_forward with contacts, Newton: every intermediate written
 void bs_launch_tpc_full_cg(BS_TPC_ARGS);  // ... CG
+void bs_launch_tpc_full_pgs(BS_TPC_ARGS); // ... PGS
+// ---- the WIDE build of the same kernels (k_tp_kernels.hip compiled with -DTP_LPE=64): one environment per
+// wavefront, nbody <= 63, up to 64 contacts per environment; grid = n_envs one-wavefront blocks.  No CHAIN instantiations.
+void bs_launch_tp_w(BS_TP_ARGS);
+void bs_launch_tp_cg_w(BS_TP_ARGS);
+void bs_launch_tp_pgs_w(BS_TP_ARGS);
+void bs_launch_tp_rk4_w(BS_TP_ARGS);
+void bs_launch_tp_rk4_cg_w(BS_TP_ARGS);
+void bs_launch_tp_rk4_pgs_w(BS_TP_ARGS);
+void bs_launch_tp_full_w(BS_TP_ARGS);
+void bs_launch_tp_full_cg_w(BS_TP_ARGS);
+void bs_launch_tp_full_pgs_w(BS_TP_ARGS);
+void bs_launch_tp_col_w(dim3 g, size_t lds, hipStream_t st, const DevModel& m, const TpModel& t, const DevData& d,
+                        const ColModel& cm, const ColData& cd);
+void bs_launch_tpc_w(BS_TPC_ARGS);
+void bs_launch_tpc_cg_w(BS_TPC_ARGS);
+void bs_launch_tpc_pgs_w(BS_TPC_ARGS);
+void bs_launch_tpc_full_w(BS_TPC_ARGS);
+void bs_launch_tpc_full_cg_w(BS_TPC_ARGS);
+void bs_launch_tpc_full_pgs_w(BS_TPC_ARGS);

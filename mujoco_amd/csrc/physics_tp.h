@@ -17,7 +17,15 @@
 #pragma once
 #include "physics_collide.h"
 
-#define TP_LPE 32   // lanes per environment
+// TP_LPE = lanes per environment.  32 (the default build): two environments per wavefront, up to 31 bodies and 32
+// contacts per environment.  64 (the WIDE build, -DTP_LPE=64, kernels k_*_w): one environment per wavefront, up to 63
+// bodies and 64 contacts — the same code with 64-bit lane masks, one more stage in the environment-wide sums and
+// two-word ancestor masks, for models and contact counts the 32-lane kernels are not eligible for.
+#ifndef TP_LPE
+#define TP_LPE 32
+#endif
+#define TP_ENVS (64 / TP_LPE)  // environments per wavefront
+#define TP_MAXLVL 66           // level tables: body depth <= 64
 #define TP_MAXD 6   // max entries in a dof's mass-matrix row (itself + 5 ancestor dofs)
 #define TP_MAXC 8   // max children per body / dof
 #define TP_NPAIR ((TP_MAXD - 1) * TP_MAXD / 2)
@@ -35,6 +43,7 @@ enum {
   TPI_COUNT = TPI_DCHILD + TP_MAXC,
   TPI_FRIC_ROW = TPI_COUNT, TPI_LIM_ROW,
   TPI_ANCMASK,  // bit k set: body lane k carries a dof on the path from this body to the root (itself included)
+  TPI_ANCMASK_HI,  // lanes 32..63 (wide build)
   TPI_TOTAL
 };
 
@@ -42,7 +51,8 @@ enum {
 // from the table in global memory into registers
 // LDS table rows (64 ints each): children 1.. of a body / dof as LANE BYTES, four per int (child 0 is held in a
 // register; "none" is stored as the environment's zero lane, so a reader needs no test), then the ancestor masks
-enum { TPL_CROWS = (TP_MAXC - 1 + 3) / 4, TPL_BCHILD = 0, TPL_DCHILD = TPL_CROWS, TPL_ANCMASK = 2 * TPL_CROWS, TPL_TOTAL = 2 * TPL_CROWS + 1 };
+enum { TPL_CROWS = (TP_MAXC - 1 + 3) / 4, TPL_BCHILD = 0, TPL_DCHILD = TPL_CROWS, TPL_ANCMASK = 2 * TPL_CROWS, TPL_ANCMASK_HI = 2 * TPL_CROWS + 1,
+       TPL_TOTAL = 2 * TPL_CROWS + (TP_LPE == 64 ? 2 : 1) };
 
 // per-lane constants of the lane's constraint rows, [field][32]: everything in mj_makeImpedance /
 // mj_referenceConstraint that does not depend on the state (K, B of the rows' solref; the whole
@@ -74,6 +84,7 @@ struct TpModel {
   const double* lane_d;  // [TPD_TOTAL][32]
   const double* lane_k;  // [32][TPK_N]
   const unsigned long long* tri_pk;  // [2][32]: row index (5 bits each) of the packed lower-triangle entries q = l + 32 t, t = 0..11 | 12..
+  const unsigned char* tri_row;      // wide build: row index of every packed entry q, one byte each
   int maxdepth, maxdd, nroots;
   int jump_rounds;  // ceil(log2(maxdepth)): pointer-jumping rounds that reach the world from every body
   int fold_minlvl;  // leaves-to-root folds (crb, rne forces) stop here: no body above this depth carries a dof
@@ -82,9 +93,9 @@ struct TpModel {
   const int* pgs_order;
   int npgs;
   int roots[4];
-  int lvl_bchild[34];          // max #children over bodies at depth L-1, indexed by child depth L
-  int lvl_next[34];            // 1: every body at depth L is the lane after its parent (chains in depth-first order): the fold is a DPP shift
-  int lvl_parent[34];          // >= 0: every body at depth L (two or more) is a child of this one body: its fold is a reduction over the lanes
+  int lvl_bchild[TP_MAXLVL];   // max #children over bodies at depth L-1, indexed by child depth L
+  int lvl_next[TP_MAXLVL];     // 1: every body at depth L is the lane after its parent (chains in depth-first order): the fold is a DPP shift
+  int lvl_parent[TP_MAXLVL];   // >= 0: every body at depth L (two or more) is a child of this one body: its fold is a reduction over the lanes
   int lvl_dchild[TP_MAXD + 2]; // max #dof-children over dofs with dd == D-1, indexed by D
   int chain;                   // 1: every dof with dd >= 3 is on the lane after its parent dof's (the CHAIN kernels apply)
 };
@@ -143,7 +154,32 @@ __device__ __forceinline__ double sum16(double v) {
   const auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(v), __double2hiint(v), false, false);
   return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
 }
-// all-reduce over the 32 lanes of an environment; every lane gets the bitwise-same sum
+// lane masks of one environment: 32 bits, or 64 in the wide build
+#if TP_LPE == 64
+typedef unsigned long long tp_mask;
+__device__ __forceinline__ int tp_ctz(tp_mask m) { return __builtin_ctzll(m); }
+__device__ __forceinline__ int tp_popc(tp_mask m) { return __popcll(m); }
+// the lanes that any environment of the wavefront has set (uniform loop bounds)
+__device__ __forceinline__ tp_mask tp_merged(unsigned long long ballot) { return ballot; }
+#else
+typedef unsigned tp_mask;
+__device__ __forceinline__ int tp_ctz(tp_mask m) { return __builtin_ctz(m); }
+__device__ __forceinline__ int tp_popc(tp_mask m) { return __popc(m); }
+__device__ __forceinline__ tp_mask tp_merged(unsigned long long ballot) { return (unsigned)(ballot | (ballot >> 32)); }
+#endif
+__device__ __forceinline__ tp_mask tp_bit(int l) { return (tp_mask)1 << l; }
+// the environment's part of a wavefront ballot (bit l = lane base + l)
+__device__ __forceinline__ tp_mask tp_env_bits(unsigned long long ballot, int base) { return (tp_mask)(ballot >> base); }
+#if TP_LPE == 64
+// v(lane) + v(lane ^ 32): v_permlane32_swap of a register with itself leaves r0 = {low half, low half} and
+// r1 = {high half, high half}, so r0 + r1 has the same operands in the same order in every lane
+__device__ __forceinline__ double sum32(double v) {
+  const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(v), __double2loint(v), false, false);
+  const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(v), __double2hiint(v), false, false);
+  return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+}
+#endif
+// all-reduce over the lanes of an environment; every lane gets the bitwise-same sum
 __device__ __forceinline__ double env_sum(double v) {
   // the argument must be rounded before the first exchange: if the compiler fused a product in the
   // caller with the first add (fma(x_i, y_i, round(x_j y_j)) in lane i, the mirror image in lane j),
@@ -154,7 +190,11 @@ __device__ __forceinline__ double env_sum(double v) {
   v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
   v += dpp_mov<0x141>(v);  // row_half_mirror
   v += dpp_mov<0x140>(v);  // row_mirror
+#if TP_LPE == 64
+  return sum32(sum16(v));
+#else
   return sum16(v);
+#endif
 }
 __device__ __forceinline__ int env_sum_i(int v) {
   v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);
@@ -162,11 +202,16 @@ __device__ __forceinline__ int env_sum_i(int v) {
   v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false);
   v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false);
   const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+#if TP_LPE == 64
+  const unsigned h = r[0] + r[1];
+  const auto q = __builtin_amdgcn_permlane32_swap(h, h, false, false);
+  return (int)(q[0] + q[1]);
+#else
   return (int)(r[0] + r[1]);
+#endif
 }
 __device__ __forceinline__ bool env_any(bool p, int base) {
-  const unsigned long long b = __ballot(p);
-  return ((b >> base) & 0xffffffffull) != 0;
+  return tp_env_bits(__ballot(p), base) != 0;
 }
 // Root-to-body recursions by pointer jumping instead of one pass per tree level: every lane
 // starts with its own term and the address of its parent's lane; a round adds (composes) what the
@@ -228,12 +273,16 @@ typedef int __attribute__((address_space(3))) * tp_lds_i;
 
 // ---- contacts in the tree-parallel layout (k_tpc): contact c of an environment is owned by lane
 // c (so at most 32 contacts); its geometry lives in an LDS slot, its rows in the lane's registers.
-#define TPC_SLOT 17                              // doubles per contact slot (odd stride)
-#define TPC_HTRI (TP_LPE * (TP_LPE + 1) / 2)     // packed lower-triangular Hessian, one per env
-#define TPC_NTRI ((TPC_HTRI + TP_LPE - 1) / TP_LPE)
-enum { CG_POS = 0, CG_FRAME = 3, CG_DIST = 12, CG_PAIR = 13, CG_D = 14, CG_MASK = 15, CG_MU = 16,  // PAIR: pair id | active rows (Newton) / row count (PGS)
-       CG_AREF = 17, CG_F = 21, CG_B = 25 };  // PGS only: aref and force of the 4 rows, B = U M^-1 U^T (nn, n1, n2, 11, 12, 22)
-#define TPC_SLOT_PGS 31                          // doubles per contact slot of k_tpc_pgs (odd stride)
+// contact slot in LDS: CG_MASK holds the ancestor masks of the contact's two bodies (two 32-bit words in one double;
+// two 64-bit words in the wide build, which shifts what follows by one double)
+__host__ __device__ constexpr int tpc_slot(int lpe) { return lpe == 64 ? 19 : 17; }       // doubles per contact slot (odd stride)
+__host__ __device__ constexpr int tpc_slot_pgs(int lpe) { return lpe == 64 ? 33 : 31; }   // ... of k_tpc_pgs (odd stride)
+#define TPC_SLOT tpc_slot(TP_LPE)
+#define TPC_SLOT_PGS tpc_slot_pgs(TP_LPE)
+#define TPC_HTRI (32 * 33 / 2)                   // 32-lane build: packed lower-triangular Hessian, one per env
+#define TPC_NTRI ((TPC_HTRI + 31) / 32)
+enum { CG_POS = 0, CG_FRAME = 3, CG_DIST = 12, CG_PAIR = 13, CG_D = 14, CG_MASK = 15, CG_MU = 15 + (TP_LPE == 64 ? 2 : 1),  // PAIR: pair id | active rows (Newton) / row count (PGS)
+       CG_AREF = CG_MU + 1, CG_F = CG_AREF + 4, CG_B = CG_F + 4 };  // PGS only: aref and force of the 4 rows, B = U M^-1 U^T (nn, n1, n2, 11, 12, 22)
 struct TpShared { int* tbl; double* H; double* cg; double* U; double* park; double* minv; };  // park: [TP_MAXD + 1][64] or null
 // per-environment M^-1 in LDS (PGS): nbody rows of (nbody | 1) doubles (odd stride: conflict-free columns)
 __host__ __device__ inline int tp_minv_stride(int nbody) { return nbody | 1; }
@@ -246,6 +295,31 @@ __host__ __device__ inline int tp_minv_stride(int nbody) { return nbody | 1; }
 __device__ __forceinline__ void tp_wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
+}
+typedef double __attribute__((address_space(3))) * tp_lds_d_;
+typedef int __attribute__((address_space(3))) * tp_lds_i_;
+// ancestor masks of a contact's two bodies in its slot
+__device__ __forceinline__ tp_mask tp_slot_mask(tp_lds_d_ sl, int which) {
+#if TP_LPE == 64
+  return ((unsigned long long __attribute__((address_space(3)))*)(sl + CG_MASK))[which];
+#else
+  return (tp_mask)((tp_lds_i_)(sl + CG_MASK))[which];
+#endif
+}
+__device__ __forceinline__ void tp_slot_mask_set(tp_lds_d_ sl, int which, tp_mask m) {
+#if TP_LPE == 64
+  ((unsigned long long __attribute__((address_space(3)))*)(sl + CG_MASK))[which] = m;
+#else
+  ((tp_lds_i_)(sl + CG_MASK))[which] = (int)m;
+#endif
+}
+// ancestor mask of body lane `lane` (wavefront lane index) from the LDS table
+__device__ __forceinline__ tp_mask tp_anc_mask(const int* tbl, int lane) {
+#if TP_LPE == 64
+  return (unsigned long long)(unsigned)tbl[TPL_ANCMASK * 64 + lane] | ((unsigned long long)(unsigned)tbl[TPL_ANCMASK_HI * 64 + lane] << 32);
+#else
+  return (tp_mask)tbl[TPL_ANCMASK * 64 + lane];
+#endif
 }
 struct TpRow { double r[TP_MAXD]; };
 struct TpFac { TpRow R; double dinv; };
@@ -917,7 +991,7 @@ __device__ __forceinline__ void tp_collide_prep(const DevModel& m, const TpModel
   COL_T(0)
   const int tid = threadIdx.x;
   const int l = tid & (TP_LPE - 1), base = tid & ~(TP_LPE - 1);
-  long env = d.env0 + (long)tp_block() * (64 / TP_LPE) + (tid / TP_LPE);
+  long env = d.env0 + (long)tp_block() * TP_ENVS + (tid / TP_LPE);
   const bool env_ok = env < d.n_envs;
   if (!env_ok) env = d.n_envs - 1;
   const long E = d.E, e = env;
@@ -991,8 +1065,8 @@ __device__ __forceinline__ void tp_collide_prep(const DevModel& m, const TpModel
   // every pair, survivors compacted IN ORDER into an LDS list; pass 2: the oriented-box filter over that list only
   // (a wavefront runs the fifteen-axis test when any of its lanes needs it: over all pairs that was every
   // trip, over the survivors it is one trip or two), then the ordered reservation of candidate slots.
-  const tp_lds_i L = (tp_lds_i)((tp_lds_d)gfr + 2 * cm.ngeom * TPG_SLOT) + (tid / TP_LPE) * cm.npair;
-  const unsigned lower = (1u << l) - 1u;
+  const tp_lds_i L = (tp_lds_i)((tp_lds_d)gfr + TP_ENVS * cm.ngeom * TPG_SLOT) + (tid / TP_LPE) * cm.npair;
+  const tp_mask lower = tp_bit(l) - 1;
   int nlist = 0;
   for (int p0 = 0; p0 < cm.npair; p0 += TP_LPE) {
     const int p = p0 + l;
@@ -1013,9 +1087,9 @@ __device__ __forceinline__ void tp_collide_prep(const DevModel& m, const TpModel
         keep = !(dot(sub(x2, x1), n) > thresh);
       }
     }
-    const unsigned mk = (unsigned)(__ballot(keep) >> base);
-    if (keep) L[nlist + __popc(mk & lower)] = p | (obb ? 1 << 30 : 0);
-    nlist += __popc(mk);
+    const tp_mask mk = tp_env_bits(__ballot(keep), base);
+    if (keep) L[nlist + tp_popc(mk & lower)] = p | (obb ? 1 << 30 : 0);
+    nlist += tp_popc(mk);
   }
   tp_wave_sync();
   int count = 0;
@@ -1040,16 +1114,16 @@ __device__ __forceinline__ void tp_collide_prep(const DevModel& m, const TpModel
     // a pair reserves pair_nsub consecutive slots (1, 2 or 8; 0 for geom types no routine handles):
     // ordered compaction with a prefix sum of the counts from three ballots
     const int cnt = keep ? cm.pair_nsub[p] : 0;
-    const unsigned m1 = (unsigned)(__ballot(cnt & 1) >> base), m2 = (unsigned)(__ballot(cnt & 2) >> base),
-                   m8 = (unsigned)(__ballot(cnt & 8) >> base);
-    const int at = count + __popc(m1 & lower) + 2 * __popc(m2 & lower) + 8 * __popc(m8 & lower);
+    const tp_mask m1 = tp_env_bits(__ballot(cnt & 1), base), m2 = tp_env_bits(__ballot(cnt & 2), base),
+                  m8 = tp_env_bits(__ballot(cnt & 8), base);
+    const int at = count + tp_popc(m1 & lower) + 2 * tp_popc(m2 & lower) + 8 * tp_popc(m8 & lower);
     if (env_ok)
       for (int q = 0; q < cnt; q++)
         if (at + q < cm.maxcand) {
           if (cd.crec) cd.crec[(size_t)e * cm.maxcand + at + q].pair = p | (q << 24);
           else AT(cd.cand_pair, at + q) = p | (q << 24);
         }
-    count += __popc(m1) + 2 * __popc(m2) + 8 * __popc(m8);
+    count += tp_popc(m1) + 2 * tp_popc(m2) + 8 * tp_popc(m8);
   }
   if (l == 0 && env_ok) {
     if (count > cm.maxcand) AT(d.warning, 0) |= 8;
@@ -1138,8 +1212,11 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
     }
   }
   tbl[TPL_ANCMASK * 64 + tid] = t.lane[TPI_ANCMASK * TP_LPE + l];
+#if TP_LPE == 64
+  tbl[TPL_ANCMASK_HI * 64 + tid] = t.lane[TPI_ANCMASK_HI * TP_LPE + l];
+#endif
   __syncthreads();
-  long env = d.env0 + (long)tp_block() * (64 / TP_LPE) + (tid / TP_LPE);
+  long env = d.env0 + (long)tp_block() * TP_ENVS + (tid / TP_LPE);
   const bool env_ok = env < d.n_envs;
   if (!env_ok) env = d.n_envs - 1;
   const long E = d.E, e = env;
@@ -1534,8 +1611,8 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
           const int sidx = s0 + l;
           const CandRec* cr = cd.crec ? cd.crec + (size_t)e * cm.maxcand + (sidx < ncand ? sidx : 0) : nullptr;
           const bool hit = sidx < ncand && (cr ? cr->hit : AT(cd.cand_hit, sidx)) != 0;
-          const unsigned bits = (unsigned)(__ballot(hit) >> base);
-          const int n = count + __popc(bits & ((1u << l) - 1u));
+          const tp_mask bits = tp_env_bits(__ballot(hit), base);
+          const int n = count + tp_popc(bits & (tp_bit(l) - 1));
           if (hit && n < cm.maxcon) {
             const int pr = (cr ? cr->pair : AT(cd.cand_pair, sidx)) & BS_PAIR_MASK;
             const double dist = cr ? cr->dist : AT(cd.cand_dist, sidx);
@@ -1563,7 +1640,7 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
               for (int k = 0; k < 9; k++) AT(cd.con_frame, 9 * n + k) = fr[k];
             }
           }
-          count += __popc(bits);
+          count += tp_popc(bits);
         }
         if (count > cm.maxcon) { count = cm.maxcon; warning |= 8; }
         ncon_env = count;
@@ -1580,8 +1657,8 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
           const int b1 = bb & 0xffff, dim = bb >> 16;
           const double* pc = cm.pair_con + (size_t)BS_PAIR_CON * pr;  // the pair's state-independent row constants
           b1_sa = (base + b1) * 4; b2_sa = (base + b2) * 4;
-          ((tp_lds_i)(myslot + CG_MASK))[0] = tbl[TPL_ANCMASK * 64 + base + b1];
-          ((tp_lds_i)(myslot + CG_MASK))[1] = tbl[TPL_ANCMASK * 64 + base + b2];
+          tp_slot_mask_set(myslot, 0, tp_anc_mask(tbl, base + b1));
+          tp_slot_mask_set(myslot, 1, tp_anc_mask(tbl, base + b2));
           cpos = {myslot[CG_POS], myslot[CG_POS + 1], myslot[CG_POS + 2]};
           const double margin = pc[0];
           const double dist = myslot[CG_DIST];
@@ -1683,17 +1760,17 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
             hasf = fn != 0;
           }
           const unsigned long long fb = __ballot(hasf);
-          const unsigned mine = (unsigned)(fb >> base);
-          unsigned merged = (unsigned)(fb | (fb >> 32));
+          const tp_mask mine = tp_env_bits(fb, base);
+          tp_mask merged = tp_merged(fb);
           while (merged) {
-            const int ci = __builtin_ctz(merged);
+            const int ci = tp_ctz(merged);
             merged &= merged - 1;
             const int sa = (base + ci) * 4;
             const V3 F = {bperm(Fw.x, sa), bperm(Fw.y, sa), bperm(Fw.z, sa)};
             if ((mine >> ci) & 1) {
               const tp_lds_d sl = slot0 + ci * SL;
-              const int m1 = ((tp_lds_i)(sl + CG_MASK))[0], m2 = ((tp_lds_i)(sl + CG_MASK))[1];
-              const int sgn = ((m2 >> l) & 1) - ((m1 >> l) & 1);
+              const tp_mask m1 = tp_slot_mask(sl, 0), m2 = tp_slot_mask(sl, 1);
+              const int sgn = (int)((m2 >> l) & 1) - (int)((m1 >> l) & 1);
               if (sgn != 0) {
                 const V3 off = {sl[CG_POS] - com.x, sl[CG_POS + 1] - com.y, sl[CG_POS + 2] - com.z};
                 const V3 tau = cross(off, F);
@@ -1732,19 +1809,19 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
               if (a < c.dd) Hrow[(c.anc_sa[a] >> 2) & (TP_LPE - 1)] = Hr.r[a];
           }
           tp_wave_sync();
-          const unsigned mine = (unsigned)(ab >> base);
-          unsigned merged = (unsigned)(ab | (ab >> 32));
+          const tp_mask mine = tp_env_bits(ab, base);
+          tp_mask merged = tp_merged(ab);
           while (merged) {
-            const int ci = __builtin_ctz(merged);
+            const int ci = tp_ctz(merged);
             merged &= merged - 1;
             const tp_lds_d sl = slot0 + ci * SL;
             double u0 = 0, u1 = 0, u2 = 0;
-            unsigned chain = 0;
+            tp_mask chain = 0;
             if ((mine >> ci) & 1) {
-              const int m1 = ((tp_lds_i)(sl + CG_MASK))[0], m2 = ((tp_lds_i)(sl + CG_MASK))[1];
-              const int sgn = ((m2 >> l) & 1) - ((m1 >> l) & 1);
+              const tp_mask m1 = tp_slot_mask(sl, 0), m2 = tp_slot_mask(sl, 1);
+              const int sgn = (int)((m2 >> l) & 1) - (int)((m1 >> l) & 1);
               if (sgn != 0) {
-                chain = (unsigned)(m1 ^ m2) & ((2u << l) - 1u);
+                chain = (m1 ^ m2) & ((tp_bit(l) << 1) - 1);
                 const V3 off = {sl[CG_POS] - com.x, sl[CG_POS + 1] - com.y, sl[CG_POS + 2] - com.z};
                 const V3 w = cross(V3{cdof[0], cdof[1], cdof[2]}, off);
                 const V3 v = {cdof[3] + w.x, cdof[4] + w.y, cdof[5] + w.z};
@@ -1768,10 +1845,10 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
               const double v1 = Cn1 * u0 + C11 * u1;
               const double v2 = Cn2 * u0 + C22 * u2;
               while (chain) {  // two entries per trip: their eight LDS reads are in flight together
-                const int k0 = __builtin_ctz(chain);
+                const int k0 = tp_ctz(chain);
                 chain &= chain - 1;
                 const bool two = chain != 0;
-                const int k1 = two ? __builtin_ctz(chain) : k0;
+                const int k1 = two ? tp_ctz(chain) : k0;
                 chain &= chain - 1;
                 const double a0 = Us[3 * k0], a1 = Us[3 * k0 + 1], a2 = Us[3 * k0 + 2], h0 = Hrow[k0];
                 const double b0 = Us[3 * k1], b1 = Us[3 * k1 + 1], b2 = Us[3 * k1 + 2], h1 = Hrow[k1];
@@ -1791,7 +1868,11 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
           // lane keeps its own entry in a register and publishes it in Gs for the panel that needs it.
           // row index of packed entry q = l + 32 t, 5 bits each (a table of ints would be spilled)
           // (host table: computed here it cost ~450 VALU instructions per launch, float sqrt + fix-ups per chunk)
+#if TP_LPE == 64
+          const unsigned char* const trow = t.tri_row;  // wide build: a byte per packed entry (33 chunks of 6 bits do not fit two words)
+#else
           const unsigned long long pk0 = t.tri_pk[l], pk1 = t.tri_pk[TP_LPE + l];  // chunks 0..11 and 12..
+#endif
           const tp_lds_d Gs = Us;  // the U staging rows are free again
           double greg = g, y = 0;
           Gs[l] = greg;
@@ -1830,14 +1911,20 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
             // the sixteen unpacked row indices out of the panel loop and spills them — reloads in here
 #pragma unroll 1
             for (int tt = 0; tt * TP_LPE < tj; tt += 2) {
+#if TP_LPE != 64
               const unsigned w = (unsigned)(tt < 12 ? pk0 >> (5 * tt) : pk1 >> (5 * (tt - 12)));
+#endif
               double h[2], ai[2], ak[2], bi[2], bk[2];
               int q[2];
 #pragma unroll
               for (int u = 0; u < 2; u++) {
                 q[u] = l + (tt + u) * TP_LPE;
                 const bool on = q[u] < tj;
+#if TP_LPE == 64
+                const int i = on ? (int)trow[q[u]] : 0;
+#else
                 const int i = on ? (int)((w >> (5 * u)) & 31u) : 0;
+#endif
                 const int k = on ? q[u] - i * (i + 1) / 2 : 0;
                 h[u] = Hs[on ? q[u] : 0];
                 ai[u] = H1[i]; ak[u] = H1[k]; bi[u] = H0[i]; bk[u] = H0[k];
@@ -1885,13 +1972,13 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
         const int mstride = tp_minv_stride(m.nbody);
         const tp_lds_d Minv = (tp_lds_d)sh.minv + (size_t)(tid / TP_LPE) * m.nbody * mstride;
         const tp_lds_d Mrow = Minv + (l < m.nbody ? l : 0) * mstride;  // lanes beyond the bodies never write
-        const unsigned dofs = (unsigned)(__ballot(has_dof) >> base);
-        for (unsigned left = dofs; left;) {  // M^-1 e_j for every dof (lane j), three columns per sweep
+        const tp_mask dofs = tp_env_bits(__ballot(has_dof), base);
+        for (tp_mask left = dofs; left;) {  // M^-1 e_j for every dof (lane j), three columns per sweep
           int col[3];
           double x[3];
 #pragma unroll
           for (int n = 0; n < 3; n++) {
-            col[n] = left ? __builtin_ctz(left) : -1;
+            col[n] = left ? tp_ctz(left) : -1;
             if (left) left &= left - 1;
             x[n] = l == col[n] ? 1.0 : 0.0;
           }
@@ -1915,14 +2002,14 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
         // kept in the contact's slot (it couples the four pyramid rows of the contact with each other)
         const int half_ = tid / TP_LPE;
         const unsigned long long conb = __ballot(CON && l < ncon_env);
-        const int ncon_max = CON ? (int)max(__popcll(conb & 0xffffffffull), __popcll(conb >> 32)) : 0;
-        auto con_u = [&](tp_lds_d sl, bool act, double& u0, double& u1, double& u2, unsigned& chain) {
+        const int ncon_max = CON ? (TP_LPE == 64 ? (int)__popcll(conb) : (int)max(__popcll(conb & 0xffffffffull), __popcll(conb >> 32))) : 0;
+        auto con_u = [&](tp_lds_d sl, bool act, double& u0, double& u1, double& u2, tp_mask& chain) {
           u0 = u1 = u2 = 0; chain = 0;
           if constexpr (CON) {
             if (act) {
-              const int m1 = ((tp_lds_i)(sl + CG_MASK))[0], m2 = ((tp_lds_i)(sl + CG_MASK))[1];
-              chain = (unsigned)(m1 ^ m2);
-              const int sgn = ((m2 >> l) & 1) - ((m1 >> l) & 1);
+              const tp_mask m1 = tp_slot_mask(sl, 0), m2 = tp_slot_mask(sl, 1);
+              chain = m1 ^ m2;
+              const int sgn = (int)((m2 >> l) & 1) - (int)((m1 >> l) & 1);
               if (sgn != 0) {
                 const V3 off = {sl[CG_POS] - com.x, sl[CG_POS + 1] - com.y, sl[CG_POS + 2] - com.z};
                 const V3 w = cross(V3{cdof[0], cdof[1], cdof[2]}, off);
@@ -1937,14 +2024,14 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
           }
         };
         // w_q[l] = sum_k M^-1[l][k] U[q][k] over the dofs k of the two chains: U staged in LDS, M^-1 row of this lane
-        auto con_w = [&](double u0, double u1, double u2, unsigned chain, double& w0, double& w1, double& w2) {
+        auto con_w = [&](double u0, double u1, double u2, tp_mask chain, double& w0, double& w1, double& w2) {
           w0 = w1 = w2 = 0;
           if constexpr (CON) {
             Us[3 * l] = u0; Us[3 * l + 1] = u1; Us[3 * l + 2] = u2;
             tp_wave_sync();
             if (l < m.nbody)
-              for (unsigned ch = chain; ch; ch &= ch - 1) {
-                const int k = __builtin_ctz(ch);
+              for (tp_mask ch = chain; ch; ch &= ch - 1) {
+                const int k = tp_ctz(ch);
                 const double mk = Mrow[k];
                 w0 += mk * Us[3 * k]; w1 += mk * Us[3 * k + 1]; w2 += mk * Us[3 * k + 2];
               }
@@ -1956,7 +2043,7 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
             const tp_lds_d sl = slot0 + ci * SL;
             const bool act = ci < ncon_env && ((tp_lds_i)(sl + CG_PAIR))[1] > 0;
             double u0, u1, u2, w0, w1, w2;
-            unsigned chain;
+            tp_mask chain;
             con_u(sl, act, u0, u1, u2, chain);
             con_w(u0, u1, u2, chain, w0, w1, w2);
             const double bnn = env_sum(u0 * w0), bn1 = env_sum(u0 * w1), bn2 = env_sum(u0 * w2), b11 = env_sum(u1 * w1),
@@ -2017,8 +2104,8 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
             tp_wave_sync();
           }
         }
-        const unsigned actF = (unsigned)(__ballot(r.Df > 0) >> base), act0 = (unsigned)(__ballot(r.Dl0 > 0) >> base),
-                       act1 = (unsigned)(__ballot(r.Dl1 > 0) >> base), actE = (unsigned)(__ballot(r.own) >> base);
+        const tp_mask actF = tp_env_bits(__ballot(r.Df > 0), base), act0 = tp_env_bits(__ballot(r.Dl0 > 0), base),
+                      act1 = tp_env_bits(__ballot(r.Dl1 > 0), base), actE = tp_env_bits(__ballot(r.own), base);
         int iter = 0;
         TPC_T(21)
         // reciprocals of D and of the diagonal of A + R once per step (the sweep is a latency chain)
@@ -2058,7 +2145,7 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
           }
           if (has_dof) acc += dl * wl;
         };
-        const unsigned actL = act0 | act1;
+        const tp_mask actL = act0 | act1;
         while (iter < m.iterations) {
           double improvement = 0;
           // efc order: equalities (host schedule: their owners are in equality order), frictionloss rows
@@ -2067,9 +2154,9 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
             const int ol = t.pgs_order[q];
             if ((actE >> ol) & 1) row(0, ol, improvement);
           }
-          for (unsigned mk = actF; mk; mk &= mk - 1) row(1, __builtin_ctz(mk), improvement);
-          for (unsigned mk = actL; mk; mk &= mk - 1) {
-            const int ol = __builtin_ctz(mk);
+          for (tp_mask mk = actF; mk; mk &= mk - 1) row(1, tp_ctz(mk), improvement);
+          for (tp_mask mk = actL; mk; mk &= mk - 1) {
+            const int ol = tp_ctz(mk);
             if ((act0 >> ol) & 1) row(2, ol, improvement);
             if ((act1 >> ol) & 1) row(3, ol, improvement);
           }
@@ -2082,7 +2169,7 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
               const int nr = ci < ncon_env ? ((tp_lds_i)(sl + CG_PAIR))[1] : 0;
               const bool act = nr > 0;
               double u0, u1, u2, w0, w1, w2;
-              unsigned chain;
+              tp_mask chain;
               con_u(sl, act, u0, u1, u2, chain);
               double jn = env_sum(u0 * acc), j1 = env_sum(u1 * acc), j2 = env_sum(u2 * acc);
               con_w(u0, u1, u2, chain, w0, w1, w2);

@@ -424,6 +424,15 @@ class BatchSim:
             _abi.check(rc)
         return bool(rc), buf.value.decode()
 
+    def footprint(self):
+        """Device memory this sim holds (bs_sim_footprint): bytes per arena, their sum and bytes per environment."""
+        out = (C.c_int64 * 5)()
+        _abi.check(_abi.lib().bs_sim_footprint(self._h, out))
+        d = dict(state=int(out[0]), contacts=int(out[1]), geom_frames=int(out[2]), serial_solver=int(out[3]))
+        d["total"] = sum(d.values())
+        d["bytes_per_env"] = d["total"] / max(1, int(out[4]))
+        return d
+
     def stream_handle(self):
         """The hipStream_t the sim's kernels are enqueued on (bs_get_stream)."""
         h = C.c_void_p()
@@ -483,7 +492,10 @@ class MixedBatchSim(BatchSim):
     on the whole batch; state and outputs are per part: `sim.parts[k].data.qpos` is
     `[n_envs_k, nq_k]`, `sim.parts[k].env_start` its first environment."""
 
-    def __init__(self, models, env_model_id=None, counts=None, device_id=0, nsubsteps=1, use_torch_stream=True):
+    def __init__(self, models, env_model_id=None, counts=None, device_id=0, nsubsteps=1, use_torch_stream=True, max_contacts=0):
+        """`max_contacts`: cap of the contact list per environment — one number for every model, or one per model
+        (0 = the library's default, 32): a model that needs a longer list (up to 64) runs the wide tree-parallel
+        kernels, the others keep the 32-lane ones."""
         if (env_model_id is None) == (counts is None):
             raise ValueError("give exactly one of env_model_id and counts")
         if counts is not None:
@@ -505,8 +517,13 @@ class MixedBatchSim(BatchSim):
         self.models = [n.model for n in self._natives]
         arr = (C.c_void_p * len(self._natives))(*[n.handle for n in self._natives])
         h = C.c_void_p()
+        caps = np.zeros(len(self._natives), dtype=np.int32)
+        caps[:] = np.asarray(max_contacts, dtype=np.int32)  # scalar or one per model
+        if (caps < 0).any():
+            raise ValueError("max_contacts must be >= 0")
+        opt = _abi.Options(max_contacts_per_env=0, max_contacts_per_model=caps.ctypes.data_as(C.POINTER(C.c_int32)))
         _abi.check(L.bs_sim_create(arr, len(self._natives), ids.ctypes.data_as(C.POINTER(C.c_int32)), self.n_envs,
-                                   self.device_id, None, C.byref(h)))
+                                   self.device_id, C.byref(opt), C.byref(h)))
         self._h = h
         self._part_model = [int(k) for k in sorted(set(ids.tolist()))]
         self.parts = [_Part(self, i) for i in range(L.bs_sim_num_parts(self._h))]

@@ -228,7 +228,12 @@ def test_config3_three_hands_4096_envs(solver):
     for mm in models:
         mm.opt_solver = SOL_NEWTON if solver == "newton" else SOL_PGS
     counts = [1366, 1365, 1365]
-    sim = MixedBatchSim(models, counts=counts)
+    # hand_1120's random poses reach more than 32 contacts in about 1 % of the environments (deep interpenetration of
+    # its stand-in meshes): that part gets a 64-contact list, i.e. the WIDE tree-parallel kernels (one environment per
+    # wavefront); the other two keep the 32-lane ones.  No environment overflows, so every sampled one is comparable.
+    sim = MixedBatchSim(models, counts=counts, max_contacts=[0, 64, 0])
+    path = sim.kernel_path()[1]
+    assert sim.kernel_path()[0] and path.count("_w") == 2 and "part 1: tree-parallel (k_tp_col_w" in path, path
     init = []
     for k, p in enumerate(sim.parts):
         q, v = workload.config2_state(models[k], p.n_envs, seed=70 + k)
@@ -240,10 +245,11 @@ def test_config3_three_hands_4096_envs(solver):
     checked = 0
     for k, p in enumerate(sim.parts):
         qg, ag = p.data.qpos.cpu().numpy(), p.data.qacc.cpu().numpy()
-        # bits 0-2 would be mj_check* resets; bit 3 (value 8) marks environments whose random pose has more
-        # than the cap of 32 contacts (deep interpenetration of the stand-in meshes of hand_1120): rare
+        # bits 0-2 would be mj_check* resets; bit 3 (value 8) a truncated contact or candidate list
         assert np.isfinite(qg).all() and int(((p.data.warning & 7) != 0).sum()) == 0
-        assert int(((p.data.warning & 8) != 0).sum()) <= p.n_envs // 100
+        assert int(((p.data.warning & 8) != 0).sum()) == 0, k
+        if k == 1:
+            assert int(p.data.ncon.max()) > 32  # the longer list is really used
         n = p.n_envs
         for e in (0, 1, 63, 64, 65, n // 2, n - 65, n - 64, n - 2, n - 1, 127, 128):
             s = OracleSim(models[k])

@@ -317,6 +317,25 @@ def test_solver_and_integrator_kwargs(hand_model):
             BatchSim(free, n_envs=E, **bad)
 
 
+def test_footprint_and_named_out_of_memory(hand_model):
+    """bs_sim_footprint: bytes per arena (the figures of the DESIGN.md section 5 table); an arena that does not fit
+    fails bs_sim_create with BS_ERR_NOMEM and a message naming it."""
+    from mujoco_amd import BatchSim, BatchSimError, workload
+    free = workload.contact_free(hand_model)
+    sim = BatchSim(free, n_envs=4096)
+    f = sim.footprint()
+    assert f["contacts"] == 0 and f["geom_frames"] == 0 and f["serial_solver"] == 0
+    assert f["state"] == f["total"] and 20_000 < f["bytes_per_env"] < 30_000
+    sim.close()
+    sim = BatchSim(workload.with_ground_plane(hand_model), n_envs=4096)
+    g = sim.footprint()
+    assert g["contacts"] > 0 and g["geom_frames"] == 4096 * 23 * 96 and g["serial_solver"] == 0
+    assert 40_000 < g["bytes_per_env"] < 60_000
+    sim.close()
+    with pytest.raises(BatchSimError, match="state arena .* bytes per environment"):
+        BatchSim(free, n_envs=40_000_000)  # ~ 1 TB of state: more than the 288 GB of an MI355X
+
+
 def test_data_of_a_destroyed_sim_raises_clearly(hand_model):
     """`sim.data` is a borrowed view: after the sim is closed or collected an access raises BatchSimError, not a bare
     ReferenceError or a use of freed device memory."""
@@ -379,20 +398,20 @@ def test_sharded_batch_sim_two_shards_one_device(hand_model):
     sh.close(); one.close()
 
 
-@pytest.mark.parametrize("solver", ["newton", "cg"])
+@pytest.mark.parametrize("solver", ["newton", "cg", "pgs"])
 def test_forward_with_contacts_writes_every_intermediate_on_tp_kernels(hand_model, solver):
-    """bs_forward of a contact model on the tree-parallel path (k_tp_col, narrowphase, k_tpc_full[_cg]): the
+    """bs_forward of a contact model on the tree-parallel path (k_tp_col, narrowphase, k_tpc_full[_cg|_pgs]): the
     intermediates a mj_forward leaves behind — poses, cinert / cdof / cvel, the fixed efc rows, forces, qacc and
     the contact list — against the oracle, and the same call again after steps."""
     import torch
     from mujoco_amd import BatchSim, workload
     from oracle import OracleSim
     m = workload.with_ground_plane(hand_model, z=-0.05)
-    if solver == "cg":
+    if solver != "newton":
         import copy
-        from mujoco_amd.model import SOL_CG
+        from mujoco_amd.model import SOL_CG, SOL_PGS
         m = copy.deepcopy(m)
-        m.opt_solver = SOL_CG
+        m.opt_solver = SOL_CG if solver == "cg" else SOL_PGS
     E = 70
     q, v = workload.config2_state(m, E, seed=31)
     v = np.random.default_rng(5).normal(size=v.shape) * 0.3
@@ -402,6 +421,8 @@ def test_forward_with_contacts_writes_every_intermediate_on_tp_kernels(hand_mode
     assert fast and "k_tpc" in path
     sim.data.qpos.copy_(torch.as_tensor(q)); sim.data.qvel.copy_(torch.as_tensor(v)); sim.data.ctrl.copy_(torch.as_tensor(c))
     sim.forward(); sim.sync()
+    # no eligible configuration allocates the serial solver's 43 KB per environment (PGS used to, round 2)
+    assert sim.footprint()["serial_solver"] == 0
     fields = ("xpos", "xquat", "rootcom", "cinert", "cdof", "cvel", "xipos", "xanchor", "xaxis", "efc_D", "efc_aref",
               "qfrc_constraint", "nefc", "qfrc_bias", "qfrc_passive", "qfrc_actuator", "qfrc_smooth", "qacc_smooth", "qacc", "ncon")
     got = {f: getattr(sim.data, f).cpu().numpy() for f in fields}
@@ -428,6 +449,9 @@ def test_forward_with_contacts_writes_every_intermediate_on_tp_kernels(hand_mode
             ref = s.efc(f[4:])[fixed]
             assert np.abs(got[f][e][rows[fixed]] - ref).max() <= tol * max(1.0, np.abs(ref).max()), (f, e)
         tol = 1e-8 if solver == "newton" else 1e-6
+        if solver == "pgs":  # efc_force of the fixed rows, straight from the sweep
+            ref = s.efc("force")[fixed]
+            assert np.abs(sim.data.efc_force.cpu().numpy()[e][rows[fixed]] - ref).max() <= 1e-6 * max(1.0, np.abs(ref).max()), e
         assert np.abs(got["qacc"][e] - s.qacc).max() <= tol * max(1.0, np.abs(s.qacc).max()), e
         assert np.abs(got["qfrc_constraint"][e] - s.qfrc_constraint).max() <= tol * max(1.0, np.abs(s.qfrc_constraint).max()), e
     assert ncon_tot > 10
