@@ -356,6 +356,10 @@ __device__ __forceinline__ double tp_up(double x, int sa, bool shift, bool recv)
   }
   return bperm(x, sa);
 }
+// The packets a level sends (T, S, U below) carry NO sender-side select: a receiver reads either its child — a
+// lane of the level that sends — or the environment's zero lane, whose rows, accumulators and right-hand side are
+// exact zeros and so are the packets it forms; what the other lanes compute at a level that is not theirs is never
+// read (round 3: the selects were 5 % of k_tp_chain's VALU instructions).
 // sparse L^T D L of the distributed rows (mj_factorM layout): R[0] diagonal, R[a] the entry with
 // the a-th ancestor dof.  Level by level from the leaves: a finished dof sends the outer-product
 // packet T(a,b) = L(k,a) M(k,b) + (packets forwarded from below) to its parent, which applies the
@@ -381,7 +385,7 @@ __device__ TP_HELPER_ATTR TpFac tp_factor(TpCtx c, TpRow Rin) {
 #pragma unroll
       for (int b = a; b < TP_MAXD; b++) {
         if (b >= D) continue;
-        T[pair_idx(a, b)] = is ? tmp * R[b] + A[pair_idx(a, b)] : 0.0;
+        T[pair_idx(a, b)] = tmp * R[b] + A[pair_idx(a, b)];
       }
       if (is) R[a] = tmp;
     }
@@ -444,10 +448,10 @@ __device__ TP_HELPER_ATTR double tp_factor_solve(TpCtx c, TpRow Rin, double x) {
 #pragma unroll
       for (int b = a; b < TP_MAXD; b++) {
         if (b >= D) continue;
-        T[pair_idx(a, b)] = is ? tmp * R[b] + A[pair_idx(a, b)] : 0.0;
+        T[pair_idx(a, b)] = tmp * R[b] + A[pair_idx(a, b)];
       }
       if (is) R[a] = tmp;
-      S[a] = is ? tmp * x + W[a] : 0.0;
+      S[a] = tmp * x + W[a];
     }
     if (is) dinv = ir0;
     if (D == 1) break;
@@ -524,7 +528,7 @@ __device__ TP_HELPER_ATTR void tp_factor2(TpCtx c, TpRow R0in, TpRow R1in, TpFac
 #pragma unroll
         for (int b = a; b < TP_MAXD; b++) {
           if (b >= D) continue;
-          T[n][pair_idx(a, b)] = is ? tmp * R[n][b] + A[n][pair_idx(a, b)] : 0.0;
+          T[n][pair_idx(a, b)] = tmp * R[n][b] + A[n][pair_idx(a, b)];
         }
         if (is) R[n][a] = tmp;
       }
@@ -574,12 +578,12 @@ __device__ TP_HELPER_ATTR double tp_solve(TpCtx c, TpRow Rin, double dinv, doubl
 #pragma unroll
   for (int D = TP_MAXD; D >= 2; D--) {
     if (D > c.maxdd) continue;
-    const bool is = c.dd == D, par = c.dd == D - 1;
+    const bool par = c.dd == D - 1;
     const bool recv = par && c.dchild0 == c.self_sa + 4;  // CHAIN: the child dof is on the next lane
     double T[TP_MAXD];
 #pragma unroll
     for (int a = 1; a < TP_MAXD; a++)
-      if (a < D) T[a] = is ? R[a] * x + W[a] : 0.0;
+      if (a < D) T[a] = R[a] * x + W[a];
     auto round = [&](int ch) {
       const int src = ch == 0 ? c.dchild0 : tp_child(c.tbl, TPL_DCHILD, ch);
       const int sa = par ? src : c.zero_sa;
@@ -644,12 +648,12 @@ __device__ TP_HELPER_ATTR double tp_solve_mulm(TpCtx c, TpRow Rin, double dinv, 
 #pragma unroll
   for (int D = TP_MAXD; D >= 2; D--) {
     if (D > c.maxdd) continue;
-    const bool is = c.dd == D, par = c.dd == D - 1;
+    const bool par = c.dd == D - 1;
     const bool recv = par && c.dchild0 == c.self_sa + 4;  // CHAIN: the child dof is on the next lane
     double T[TP_MAXD], U[TP_MAXD];
 #pragma unroll
     for (int a = 1; a < TP_MAXD; a++)
-      if (a < D) { T[a] = is ? R[a] * x + W[a] : 0.0; U[a] = is ? Mr[a] * v + V[a] : 0.0; }
+      if (a < D) { T[a] = R[a] * x + W[a]; U[a] = Mr[a] * v + V[a]; }
     auto round = [&](int ch) {
       const int src = ch == 0 ? c.dchild0 : tp_child(c.tbl, TPL_DCHILD, ch);
       const int sa = par ? src : c.zero_sa;
@@ -700,14 +704,14 @@ __device__ TP_HELPER_ATTR void tp_solve_n(TpCtx c, TpRow Rin, double dinv, doubl
 #pragma unroll
   for (int D = TP_MAXD; D >= 2; D--) {
     if (D > c.maxdd) continue;
-    const bool is = c.dd == D, par = c.dd == D - 1;
+    const bool par = c.dd == D - 1;
     const bool recv = par && c.dchild0 == c.self_sa + 4;  // CHAIN: the child dof is on the next lane
     double T[N][TP_MAXD];
 #pragma unroll
     for (int n = 0; n < N; n++)
 #pragma unroll
       for (int a = 1; a < TP_MAXD; a++)
-        if (a < D) T[n][a] = is ? R[a] * x[n] + W[n][a] : 0.0;
+        if (a < D) T[n][a] = R[a] * x[n] + W[n][a];
     auto round = [&](int ch) {
       const int src = ch == 0 ? c.dchild0 : tp_child(c.tbl, TPL_DCHILD, ch);
       const int sa = par ? src : c.zero_sa;
@@ -773,12 +777,12 @@ __device__ TP_HELPER_ATTR double tp_mul_m(TpCtx c, TpRow Min, double v) {
 #pragma unroll
   for (int D = TP_MAXD; D >= 2; D--) {
     if (D > c.maxdd) continue;
-    const bool is = c.dd == D, par = c.dd == D - 1;
+    const bool par = c.dd == D - 1;
     const bool recv = par && c.dchild0 == c.self_sa + 4;  // CHAIN: the child dof is on the next lane
     double T[TP_MAXD];
 #pragma unroll
     for (int a = 1; a < TP_MAXD; a++)
-      if (a < D) T[a] = is ? Mr[a] * v + W[a] : 0.0;
+      if (a < D) T[a] = Mr[a] * v + W[a];
     auto round = [&](int ch) {
       const int src = ch == 0 ? c.dchild0 : tp_child(c.tbl, TPL_DCHILD, ch);
       const int sa = par ? src : c.zero_sa;
