@@ -139,10 +139,14 @@ __device__ __forceinline__ double bperm(double v, int sa) {
   const int hi = __builtin_amdgcn_ds_bpermute(sa, __double2hiint(v));
   return __hiloint2double(hi, lo);
 }
+// A double moves as two v_mov_b32_dpp (a 64-bit DPP move only encodes row_newbcast on gfx950: llvm-mc, "DP ALU dpp
+// only supports row_newbcast").  bound_ctrl:1 on purpose: a lane whose source is out of range or disabled reads 0 —
+// the same value as `old = 0` with bound_ctrl:0 — but with bound_ctrl:0 the compiler has to load that 0 into the
+// destination with a v_mov_b32 in front of EVERY DPP move (round 3: that was one VALU instruction in eight of k_tp_chain).
 template <int CTRL>
 __device__ __forceinline__ double dpp_mov(double v) {
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
   return __hiloint2double(hi, lo);
 }
 // v(lane) + v(lane ^ 16) inside each 32-lane half with gfx950's v_permlane16_swap (a VALU instruction:
@@ -197,10 +201,10 @@ __device__ __forceinline__ double env_sum(double v) {
 #endif
 }
 __device__ __forceinline__ int env_sum_i(int v) {
-  v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);
-  v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);
-  v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false);
-  v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, true);
   const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
 #if TP_LPE == 64
   const unsigned h = r[0] + r[1];
