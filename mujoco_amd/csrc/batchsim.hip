@@ -159,6 +159,7 @@ static void build_tp(bs_model* mdl, int variant) {
   for (int j = 0; j < nv; j++)
     if (dd[j] >= 3 && s.dof_bodyid[s.dof_parentid[j]] != s.dof_bodyid[j] - 1) m->tp.chain = 0;
   if (getenv("BS_NO_CHAIN") || variant) m->tp.chain = 0;  // the wide build has no CHAIN instantiations
+  if (m->tp.lvl_dchild[2] > TP_CHAIN_MAXC) m->tp.chain = 0;  // more child chains than the CHAIN kernels unroll
   // levels whose bodies all sit on the lane after their parent's
   for (int L = 0; L < TP_MAXLVL; L++) m->tp.lvl_next[L] = 0;
   for (int L = 2; L <= maxdepth && L < TP_MAXLVL; L++) {

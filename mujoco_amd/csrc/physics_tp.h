@@ -29,6 +29,10 @@
 #define TP_MAXD 6   // max entries in a dof's mass-matrix row (itself + 5 ancestor dofs)
 #define TP_MAXC 8   // max children per body / dof
 #define TP_NPAIR ((TP_MAXD - 1) * TP_MAXD / 2)
+// CHAIN instantiations unroll the child rounds of the branching level (the dofs hanging off the root dof: a hand's
+// fingers) to this many: models with more children there run the generic kernels.  Unrolled to TP_MAXC = 8 a
+// five-fingered hand spent three of eight rounds of every sweep fetching zeros from the zero lane.
+#define TP_CHAIN_MAXC 5
 
 #ifndef TP_HELPER_ATTR
 #define TP_HELPER_ATTR __forceinline__
@@ -415,7 +419,7 @@ __device__ TP_HELPER_ATTR TpFac tp_factor(TpCtx c, TpRow Rin) {
     if (CHAIN && D == 2) {  // the branching level: every child's fetch issued before the first accumulation (table
                             // entries beyond the children name the zero lane), same order of accumulation
 #pragma unroll
-      for (int ch = 0; ch < TP_MAXC; ch++) round(ch);
+      for (int ch = 0; ch < TP_CHAIN_MAXC; ch++) round(ch);
     } else {
       for (int ch = 0; ch < (CHAIN && D >= 3 ? 1 : c.nchild[D]); ch++) round(ch);
     }
@@ -482,7 +486,7 @@ __device__ TP_HELPER_ATTR double tp_factor_solve(TpCtx c, TpRow Rin, double x) {
     if (CHAIN && D == 2) {  // the branching level: every child's fetch issued before the first accumulation (table
                             // entries beyond the children name the zero lane), same order of accumulation
 #pragma unroll
-      for (int ch = 0; ch < TP_MAXC; ch++) round(ch);
+      for (int ch = 0; ch < TP_CHAIN_MAXC; ch++) round(ch);
     } else {
       for (int ch = 0; ch < (CHAIN && D >= 3 ? 1 : c.nchild[D]); ch++) round(ch);
     }
@@ -562,7 +566,7 @@ __device__ TP_HELPER_ATTR void tp_factor2(TpCtx c, TpRow R0in, TpRow R1in, TpFac
     if (CHAIN && D == 2) {  // the branching level: every child's fetch issued before the first accumulation (table
                             // entries beyond the children name the zero lane), same order of accumulation
 #pragma unroll
-      for (int ch = 0; ch < TP_MAXC; ch++) round(ch);
+      for (int ch = 0; ch < TP_CHAIN_MAXC; ch++) round(ch);
     } else {
       for (int ch = 0; ch < (CHAIN && D >= 3 ? 1 : c.nchild[D]); ch++) round(ch);
     }
@@ -602,7 +606,7 @@ __device__ TP_HELPER_ATTR double tp_solve(TpCtx c, TpRow Rin, double dinv, doubl
     if (CHAIN && D == 2) {  // the branching level: every child's fetch issued before the first accumulation (table
                             // entries beyond the children name the zero lane), same order of accumulation
 #pragma unroll
-      for (int ch = 0; ch < TP_MAXC; ch++) round(ch);
+      for (int ch = 0; ch < TP_CHAIN_MAXC; ch++) round(ch);
     } else {
       for (int ch = 0; ch < (CHAIN && D >= 3 ? 1 : c.nchild[D]); ch++) round(ch);
     }
@@ -672,7 +676,7 @@ __device__ TP_HELPER_ATTR double tp_solve_mulm(TpCtx c, TpRow Rin, double dinv, 
     if (CHAIN && D == 2) {  // the branching level: every child's fetch issued before the first accumulation (table
                             // entries beyond the children name the zero lane), same order of accumulation
 #pragma unroll
-      for (int ch = 0; ch < TP_MAXC; ch++) round(ch);
+      for (int ch = 0; ch < TP_CHAIN_MAXC; ch++) round(ch);
     } else {
       for (int ch = 0; ch < (CHAIN && D >= 3 ? 1 : c.nchild[D]); ch++) round(ch);
     }
@@ -733,7 +737,7 @@ __device__ TP_HELPER_ATTR void tp_solve_n(TpCtx c, TpRow Rin, double dinv, doubl
     if (CHAIN && D == 2) {  // the branching level: every child's fetch issued before the first accumulation (table
                             // entries beyond the children name the zero lane), same order of accumulation
 #pragma unroll
-      for (int ch = 0; ch < TP_MAXC; ch++) round(ch);
+      for (int ch = 0; ch < TP_CHAIN_MAXC; ch++) round(ch);
     } else {
       for (int ch = 0; ch < (CHAIN && D >= 3 ? 1 : c.nchild[D]); ch++) round(ch);
     }
@@ -801,7 +805,7 @@ __device__ TP_HELPER_ATTR double tp_mul_m(TpCtx c, TpRow Min, double v) {
     if (CHAIN && D == 2) {  // the branching level: every child's fetch issued before the first accumulation (table
                             // entries beyond the children name the zero lane), same order of accumulation
 #pragma unroll
-      for (int ch = 0; ch < TP_MAXC; ch++) round(ch);
+      for (int ch = 0; ch < TP_CHAIN_MAXC; ch++) round(ch);
     } else {
       for (int ch = 0; ch < (CHAIN && D >= 3 ? 1 : c.nchild[D]); ch++) round(ch);
     }
