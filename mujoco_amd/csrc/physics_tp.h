@@ -344,6 +344,8 @@ struct TpCtx {
   int top_sa;            // address of the lane's (dd - 1)-th ancestor dof: the one above its chain (CHAIN kernels)
   int dchild0;           // first entry of the lane's dof-child list (the LDS table's row 0): most levels have one child,
                          // so the sweeps' usual case needs no table read in front of the permutes
+  int dchild_w;          // dof-children 1..4 as lane bytes (row TPL_DCHILD of the LDS table), in a register for the CHAIN
+                         // kernels' branching level: no table read in front of its fetches
   tp_lds_ptr tbl;        // LDS table
 };
 // ds_bpermute address of child ch >= 1 of this lane (row0 = TPL_BCHILD or TPL_DCHILD)
@@ -351,6 +353,9 @@ __device__ __forceinline__ int tp_child(tp_lds_ptr tbl, int row0, int ch) {
   const int w = tbl[(row0 + ((ch - 1) >> 2)) * 64 + threadIdx.x];
   return ((w >> (((ch - 1) & 3) * 8)) & 0xff) << 2;
 }
+
+static_assert(TP_CHAIN_MAXC <= 5, "tp_child_w holds children 1..4");
+__device__ __forceinline__ int tp_child_w(int w, int ch) { return ((w >> ((ch - 1) * 8)) & 0xff) << 2; }
 
 // what a parent dof receives from its child in a leaves-to-root sweep: a ds_bpermute per value, or — in the CHAIN
 // instantiation, on the levels below the first branching (TpModel::chain: every dof of level D >= 3 sits on the lane
@@ -402,7 +407,7 @@ __device__ TP_HELPER_ATTR TpFac tp_factor(TpCtx c, TpRow Rin) {
     const bool par = c.dd == D - 1;
     const bool recv = par && c.dchild0 == c.self_sa + 4;  // CHAIN: the child dof is on the next lane
     auto round = [&](int ch) {
-      const int src = ch == 0 ? c.dchild0 : tp_child(c.tbl, TPL_DCHILD, ch);
+      const int src = ch == 0 ? c.dchild0 : (CHAIN && D == 2 ? tp_child_w(c.dchild_w, ch) : tp_child(c.tbl, TPL_DCHILD, ch));
       const int sa = par ? src : c.zero_sa;
 #pragma unroll
       for (int a = 1; a < TP_MAXD; a++) {
@@ -466,7 +471,7 @@ __device__ TP_HELPER_ATTR double tp_factor_solve(TpCtx c, TpRow Rin, double x) {
     const bool par = c.dd == D - 1;
     const bool recv = par && c.dchild0 == c.self_sa + 4;  // CHAIN: the child dof is on the next lane
     auto round = [&](int ch) {
-      const int src = ch == 0 ? c.dchild0 : tp_child(c.tbl, TPL_DCHILD, ch);
+      const int src = ch == 0 ? c.dchild0 : (CHAIN && D == 2 ? tp_child_w(c.dchild_w, ch) : tp_child(c.tbl, TPL_DCHILD, ch));
       const int sa = par ? src : c.zero_sa;
 #pragma unroll
       for (int a = 1; a < TP_MAXD; a++) {
@@ -546,7 +551,7 @@ __device__ TP_HELPER_ATTR void tp_factor2(TpCtx c, TpRow R0in, TpRow R1in, TpFac
     const bool par = c.dd == D - 1;
     const bool recv = par && c.dchild0 == c.self_sa + 4;  // CHAIN: the child dof is on the next lane
     auto round = [&](int ch) {
-      const int src = ch == 0 ? c.dchild0 : tp_child(c.tbl, TPL_DCHILD, ch);
+      const int src = ch == 0 ? c.dchild0 : (CHAIN && D == 2 ? tp_child_w(c.dchild_w, ch) : tp_child(c.tbl, TPL_DCHILD, ch));
       const int sa = par ? src : c.zero_sa;
 #pragma unroll
       for (int a = 1; a < TP_MAXD; a++) {
@@ -593,7 +598,7 @@ __device__ TP_HELPER_ATTR double tp_solve(TpCtx c, TpRow Rin, double dinv, doubl
     for (int a = 1; a < TP_MAXD; a++)
       if (a < D) T[a] = R[a] * x + W[a];
     auto round = [&](int ch) {
-      const int src = ch == 0 ? c.dchild0 : tp_child(c.tbl, TPL_DCHILD, ch);
+      const int src = ch == 0 ? c.dchild0 : (CHAIN && D == 2 ? tp_child_w(c.dchild_w, ch) : tp_child(c.tbl, TPL_DCHILD, ch));
       const int sa = par ? src : c.zero_sa;
 #pragma unroll
       for (int a = 1; a < TP_MAXD; a++) {
@@ -663,7 +668,7 @@ __device__ TP_HELPER_ATTR double tp_solve_mulm(TpCtx c, TpRow Rin, double dinv, 
     for (int a = 1; a < TP_MAXD; a++)
       if (a < D) { T[a] = R[a] * x + W[a]; U[a] = Mr[a] * v + V[a]; }
     auto round = [&](int ch) {
-      const int src = ch == 0 ? c.dchild0 : tp_child(c.tbl, TPL_DCHILD, ch);
+      const int src = ch == 0 ? c.dchild0 : (CHAIN && D == 2 ? tp_child_w(c.dchild_w, ch) : tp_child(c.tbl, TPL_DCHILD, ch));
       const int sa = par ? src : c.zero_sa;
 #pragma unroll
       for (int a = 1; a < TP_MAXD; a++) {
@@ -721,7 +726,7 @@ __device__ TP_HELPER_ATTR void tp_solve_n(TpCtx c, TpRow Rin, double dinv, doubl
       for (int a = 1; a < TP_MAXD; a++)
         if (a < D) T[n][a] = R[a] * x[n] + W[n][a];
     auto round = [&](int ch) {
-      const int src = ch == 0 ? c.dchild0 : tp_child(c.tbl, TPL_DCHILD, ch);
+      const int src = ch == 0 ? c.dchild0 : (CHAIN && D == 2 ? tp_child_w(c.dchild_w, ch) : tp_child(c.tbl, TPL_DCHILD, ch));
       const int sa = par ? src : c.zero_sa;
 #pragma unroll
       for (int a = 1; a < TP_MAXD; a++) {
@@ -792,7 +797,7 @@ __device__ TP_HELPER_ATTR double tp_mul_m(TpCtx c, TpRow Min, double v) {
     for (int a = 1; a < TP_MAXD; a++)
       if (a < D) T[a] = Mr[a] * v + W[a];
     auto round = [&](int ch) {
-      const int src = ch == 0 ? c.dchild0 : tp_child(c.tbl, TPL_DCHILD, ch);
+      const int src = ch == 0 ? c.dchild0 : (CHAIN && D == 2 ? tp_child_w(c.dchild_w, ch) : tp_child(c.tbl, TPL_DCHILD, ch));
       const int sa = par ? src : c.zero_sa;
 #pragma unroll
       for (int a = 1; a < TP_MAXD; a++) {
@@ -1247,6 +1252,7 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
   c.self_sa = self_sa; c.zero_sa = (base + TP_LPE - 1) * 4; c.dd = has_dof ? t.lane[TPI_DD * TP_LPE + l] : 0; c.maxdd = t.maxdd; c.tbl = (tp_lds_ptr)tbl;
   c.dchild0 = lane_ref(TPI_DCHILD);
   if (c.dchild0 < 0) c.dchild0 = (base + TP_LPE - 1) * 4;
+  c.dchild_w = tbl[TPL_DCHILD * 64 + tid];  // (after the barrier below; the CHAIN kernels keep it for the whole launch)
   int bchild0 = lane_ref(TPI_BCHILD);
   if (bchild0 < 0) bchild0 = (base + TP_LPE - 1) * 4;
 #pragma unroll
