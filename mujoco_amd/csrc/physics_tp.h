@@ -16,6 +16,7 @@
 // Stage semantics and reference citations are those of physics_dev.h.
 #pragma once
 #include "physics_collide.h"
+#include <type_traits>
 
 // TP_LPE = lanes per environment.  32 (the default build): two environments per wavefront, up to 31 bodies and 32
 // contacts per environment.  64 (the WIDE build, -DTP_LPE=64, kernels k_*_w): one environment per wavefront, up to 63
@@ -1610,12 +1611,19 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
           }
         }
       };
-      auto con_rows = [&](const double* u3, double sub, double* out) {
-        out[0] = cnr > 0 ? (u3[0] + cmu * u3[1]) - sub * caref[0] : 0.0;
-        out[1] = cnr > 1 ? (u3[0] - cmu * u3[1]) - sub * caref[1] : 0.0;
-        out[2] = cnr > 1 ? (u3[0] + cmu * u3[2]) - sub * caref[2] : 0.0;
-        out[3] = cnr > 1 ? (u3[0] - cmu * u3[2]) - sub * caref[3] : 0.0;
+      // SUB: subtract aref (residuals J a - aref) or not (J x).  A compile-time flag on purpose: written as
+      // `- sub * caref` with sub = 0.0 the products cannot be folded away (0 * x is not 0 for every x), so aref of
+      // the fixed rows and of the contact stayed live through the whole Newton loop — eight doubles per lane, reloaded
+      // from scratch in every iteration to be multiplied by zero (round 3)
+      auto con_rows = [&](const double* u3, auto SUB, double* out) {
+        constexpr bool sub = decltype(SUB)::value;
+        out[0] = cnr > 0 ? (sub ? (u3[0] + cmu * u3[1]) - caref[0] : (u3[0] + cmu * u3[1])) : 0.0;
+        out[1] = cnr > 1 ? (sub ? (u3[0] - cmu * u3[1]) - caref[1] : (u3[0] - cmu * u3[1])) : 0.0;
+        out[2] = cnr > 1 ? (sub ? (u3[0] + cmu * u3[2]) - caref[2] : (u3[0] + cmu * u3[2])) : 0.0;
+        out[3] = cnr > 1 ? (sub ? (u3[0] - cmu * u3[2]) - caref[3] : (u3[0] - cmu * u3[2])) : 0.0;
       };
+      constexpr std::true_type WITH_AREF{};
+      constexpr std::false_type NO_AREF{};
       if constexpr (CON) {
         const int half = tid / TP_LPE;
         slot0 = (tp_lds_d)sh.cg + half * (TP_LPE * SL);
@@ -1698,7 +1706,7 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
         }
         double u3[3], vel[4];
         con_jx(qvel, u3);
-        con_rows(u3, 0.0, vel);
+        con_rows(u3, NO_AREF, vel);
 #pragma unroll
         for (int q = 0; q < 4; q++) caref[q] = q < cnr ? -cB * vel[q] - ckimp : 0.0;
         if constexpr (PGS) {
@@ -2092,7 +2100,7 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
           if constexpr (CON) {  // contact rows: f = -D min(J qacc_ws - aref, 0)
             double u3[3], cjt[4];
             con_jx(qacc_ws, u3);
-            con_rows(u3, 1.0, cjt);
+            con_rows(u3, WITH_AREF, cjt);
             tp_con_cost<true>(r.cD, cjt, cfo);
           }
           double jt = jtf();
@@ -2103,8 +2111,8 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
           if constexpr (CON) {
             double ua[3], ub[3], jw[4], js[4];
             con_jx2(w, qacc_smooth, ua, ub);
-            con_rows(ua, 0.0, jw);   // J_r w
-            con_rows(ub, 1.0, js);   // J_r qacc_smooth - aref_r
+            con_rows(ua, NO_AREF, jw);   // J_r w
+            con_rows(ub, WITH_AREF, js);   // J_r qacc_smooth - aref_r
 #pragma unroll
             for (int q = 0; q < 4; q++)
               if (q < cnr) cl += cfo[q] * (0.5 * (jw[q] + cfo[q] / r.cD) + js[q]);
@@ -2240,17 +2248,23 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
         TpSol s;
 #pragma unroll
         for (int q = 0; q < 4; q++) { s.cj[q] = 0; s.cv[q] = 0; }
-        auto residual_fixed = [&](double a, double sub, double& jf, double& jl0, double& jl1, double& je) {
+        auto residual_fixed = [&](double a, auto SUB, double& jf, double& jl0, double& jl1, double& je) {
+          constexpr bool sub = decltype(SUB)::value;
           const double ao = bperm(a, eq_other_sa);
-          jf = a - sub * r.aref_f; jl0 = a - sub * r.aref_l0; jl1 = -a - sub * r.aref_l1;
-          je = r.own ? (a - r.ce * ao) - sub * r.aref_e : 0.0;
+          if constexpr (sub) {
+            jf = a - r.aref_f; jl0 = a - r.aref_l0; jl1 = -a - r.aref_l1;
+            je = r.own ? (a - r.ce * ao) - r.aref_e : 0.0;
+          } else {
+            jf = a; jl0 = a; jl1 = -a;
+            je = r.own ? (a - r.ce * ao) : 0.0;
+          }
         };
-        auto residual = [&](double a, double sub, double& jf, double& jl0, double& jl1, double& je, double* cjr) {
-          residual_fixed(a, sub, jf, jl0, jl1, je);
+        auto residual = [&](double a, auto SUB, double& jf, double& jl0, double& jl1, double& je, double* cjr) {
+          residual_fixed(a, SUB, jf, jl0, jl1, je);
           if constexpr (CON) {
             double u3[3];
             con_jx(a, u3);
-            con_rows(u3, sub, cjr);
+            con_rows(u3, SUB, cjr);
           }
         };
         // warm start: previous acceleration only if cheaper than the unconstrained one
@@ -2263,15 +2277,15 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
           double wf, wl0, wl1, we, wc[4] = {0, 0, 0, 0};
           const bool ws_on = !(m.disableflags & BS_DSBL_WARMSTART);
           if (CON && ws_on) {
-            residual_fixed(qacc_smooth, 1.0, s.jf, s.jl0, s.jl1, s.je);
-            residual_fixed(qacc_ws, 1.0, wf, wl0, wl1, we);
+            residual_fixed(qacc_smooth, WITH_AREF, s.jf, s.jl0, s.jl1, s.je);
+            residual_fixed(qacc_ws, WITH_AREF, wf, wl0, wl1, we);
             double ua[3], ub[3];
             con_jx2(qacc_smooth, qacc_ws, ua, ub);
-            con_rows(ua, 1.0, s.cj);
-            con_rows(ub, 1.0, wc);
+            con_rows(ua, WITH_AREF, s.cj);
+            con_rows(ub, WITH_AREF, wc);
           } else {
-            residual(qacc_smooth, 1.0, s.jf, s.jl0, s.jl1, s.je, s.cj);
-            if (ws_on) residual(qacc_ws, 1.0, wf, wl0, wl1, we, wc);
+            residual(qacc_smooth, WITH_AREF, s.jf, s.jl0, s.jl1, s.je, s.cj);
+            if (ws_on) residual(qacc_ws, WITH_AREF, wf, wl0, wl1, we, wc);
           }
           if (ws_on) {
             double cl = tp_rows_cost<false>(r, wf, wl0, wl1, we, nullptr) +
@@ -2363,7 +2377,7 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
           TPC_T(9)
           s.Mv = tp_mul_m<CHAIN>(c, Mr, s.search);
           TPC_C(23)
-          residual(s.search, 0.0, s.vf, s.vl0, s.vl1, s.ve, s.cv);
+          residual(s.search, NO_AREF, s.vf, s.vl0, s.vl1, s.ve, s.cv);
           TPC_C(24)
           const double alpha = tp_line_search<CON>(m, r, s, gauss, scale, qfrc_smooth);
           if (alpha == 0) break;
