@@ -508,7 +508,7 @@ __device__ TP_HELPER_ATTR double tp_factor_solve(TpCtx c, TpRow Rin, double x) {
       if (a >= D) continue;
       double xa;
       if (CHAIN && a <= D - 2) { xs = dpp_mov<0x138>(xs); xa = xs; }  // wave_shr:1
-      else xa = bperm(x, c.anc_sa[a]);
+      else xa = bperm(x, CHAIN ? c.top_sa : c.anc_sa[a]);  // CHAIN: a == D - 1, the dof above the chain
       if (is) x -= R[a] * xa;
     }
   }
@@ -628,7 +628,7 @@ __device__ TP_HELPER_ATTR double tp_solve(TpCtx c, TpRow Rin, double dinv, doubl
       if (a >= D) continue;
       double xa;
       if (CHAIN && a <= D - 2) { xs = dpp_mov<0x138>(xs); xa = xs; }  // wave_shr:1
-      else xa = bperm(x, c.anc_sa[a]);
+      else xa = bperm(x, CHAIN ? c.top_sa : c.anc_sa[a]);  // CHAIN: a == D - 1, the dof above the chain
       if (is) x -= R[a] * xa;
     }
   }
@@ -699,7 +699,7 @@ __device__ TP_HELPER_ATTR double tp_solve_mulm(TpCtx c, TpRow Rin, double dinv, 
       if (a >= D) continue;
       double xa;
       if (CHAIN && a <= D - 2) { xs = dpp_mov<0x138>(xs); xa = xs; }  // wave_shr:1
-      else xa = bperm(x, c.anc_sa[a]);
+      else xa = bperm(x, CHAIN ? c.top_sa : c.anc_sa[a]);  // CHAIN: a == D - 1, the dof above the chain
       if (is) x -= R[a] * xa;
     }
   }
@@ -1830,9 +1830,18 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
           const tp_lds_d Hrow = Hs + l * (l + 1) / 2;
           if (l < n) {
             Hrow[l] = Hr.r[0];
+            // the ancestor lanes are recomputed here in every Newton iteration: left to itself the compiler hoists the
+            // five LDS addresses out of the solver loop, spills them, and reloads them from scratch in each iteration
+            int self_sa_it = c.self_sa, top_sa_it = c.top_sa, dd_it = c.dd;
+            asm volatile("" : "+v"(self_sa_it), "+v"(top_sa_it), "+v"(dd_it));
 #pragma unroll
             for (int a = 1; a < TP_MAXD; a++)
-              if (a < c.dd) Hrow[(c.anc_sa[a] >> 2) & (TP_LPE - 1)] = Hr.r[a];
+              if (a < dd_it) {
+                // lane of the a-th ancestor dof; CHAIN models: a lanes below, or the dof above the chain — computed, so
+                // that the six ancestor addresses need not stay live (they were reloaded from scratch here every iteration)
+                const int asa = CHAIN ? (a == dd_it - 1 ? top_sa_it : self_sa_it - 4 * a) : c.anc_sa[a];
+                Hrow[(asa >> 2) & (TP_LPE - 1)] = Hr.r[a];
+              }
           }
           tp_wave_sync();
           const tp_mask mine = tp_env_bits(ab, base);
