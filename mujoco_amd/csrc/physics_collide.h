@@ -18,11 +18,13 @@
 enum { BS_GEOM_PLANE = 0, BS_GEOM_HFIELD = 1, BS_GEOM_SPHERE = 2, BS_GEOM_CAPSULE = 3, BS_GEOM_ELLIPSOID = 4,
        BS_GEOM_CYLINDER = 5, BS_GEOM_BOX = 6, BS_GEOM_MESH = 7 };
 // a candidate slot names one potential contact: pair id in the low 24 bits, sub-contact in the high 8
-// (plane-capsule: 2 cap centres, plane-box: 8 corners, every other pair: 1)
+// (plane-capsule: 2 cap centres, plane-box: 8 corners of which at most 4 make a contact, capsule-capsule: 2 for
+// parallel axes, every other pair: 1)
 #define BS_PAIR_MASK 0xFFFFFF
 __host__ __device__ inline int pair_nsub_types(int t1, int t2) {
   if (t1 == BS_GEOM_PLANE && t2 == BS_GEOM_CAPSULE) return 2;
   if (t1 == BS_GEOM_PLANE && t2 == BS_GEOM_BOX) return 8;
+  if (t1 == BS_GEOM_CAPSULE && t2 == BS_GEOM_CAPSULE) return 2;
   return 1;
 }
 __host__ __device__ inline bool pair_supported_types(int t1, int t2) {  // t1 <= t2 (model.py::_build_pairs)
@@ -612,6 +614,39 @@ __device__ inline void seg_seg_closest(const V3& c1, const V3& a1, double h1, co
   p2 = {c2.x + t2 * a2.x, c2.y + t2 * a2.y, c2.z + t2 * a2.z};
 }
 
+// capsule - capsule, sub-contact `sub` (same closed form as oracle_collide.c::capsule_capsule): one contact for axes in
+// general position; for (near-)parallel axes up to two — the ends of each segment against the closest point of the
+// other, in the order +end / -end of capsule 1, then of capsule 2, until two have been found
+__device__ inline bool capsule_capsule(const V3& c1, const V3& a1, double h1, double r1, const V3& c2, const V3& a2, double h2,
+                                       double r2, double margin, int sub, double& dist, V3& pos, V3& nrm) {
+  const V3 w = sub3(c1, c2);
+  const double b = dot(a1, a2), d1 = dot(a1, w), d2 = dot(a2, w), den = 1 - b * b;
+  if (den > 1e-12) {
+    if (sub != 0) return false;
+    V3 p1, p2;
+    seg_seg_closest(c1, a1, h1, c2, a2, h2, p1, p2);
+    return sphere_sphere(p1, r1, p2, r2, margin, dist, pos, nrm);
+  }
+  int found = 0;
+  for (int k = 0; k < 4 && found < 2; k++) {
+    double t1, t2;
+    if (k < 2) {
+      t1 = k == 0 ? h1 : -h1;
+      t2 = d2 + b * t1;
+      t2 = t2 > h2 ? h2 : (t2 < -h2 ? -h2 : t2);
+    } else {
+      t2 = k == 2 ? h2 : -h2;
+      t1 = b * t2 - d1;
+      t1 = t1 > h1 ? h1 : (t1 < -h1 ? -h1 : t1);
+    }
+    const V3 p1 = {c1.x + t1 * a1.x, c1.y + t1 * a1.y, c1.z + t1 * a1.z}, p2 = {c2.x + t2 * a2.x, c2.y + t2 * a2.y, c2.z + t2 * a2.z};
+    if (!sphere_sphere(p1, r1, p2, r2, margin, dist, pos, nrm)) continue;
+    if (found == sub) return true;
+    found++;
+  }
+  return false;
+}
+
 // ---------------------------------------------------------------- kernels' bodies
 // geom frames for one environment lane (same arithmetic as k_frames, geoms only)
 __device__ inline void col_geom_frames(const DevModel& m, const DevData& d, const ColData& c, long e) {
@@ -751,12 +786,24 @@ __device__ inline void col_narrowphase(const ColModel& cm, const DevData& d, con
     if (t1 == BS_GEOM_PLANE && (t2 == BS_GEOM_CAPSULE || t2 == BS_GEOM_BOX)) {
       const V3 n = {AT(c.geom_xmat, 9 * g1 + 2), AT(c.geom_xmat, 9 * g1 + 5), AT(c.geom_xmat, 9 * g1 + 8)};
       const V3 pp = {AT(c.geom_xpos, 3 * g1), AT(c.geom_xpos, 3 * g1 + 1), AT(c.geom_xpos, 3 * g1 + 2)};
-      V3 v;
-      double r = 0;
-      if (t2 == BS_GEOM_CAPSULE) { v = {0, 0, sub == 0 ? b.size.y : -b.size.y}; r = b.size.x; }  // cap centre +axis, then -axis
-      else v = {sub & 1 ? -b.size.x : b.size.x, sub & 2 ? -b.size.y : b.size.y, sub & 4 ? -b.size.z : b.size.z};
-      const V3 w = mrot(b.R, v);
-      hit = plane_point(pp, n, V3{b.xpos.x + w.x, b.xpos.y + w.y, b.xpos.z + w.z}, r, margin, dist, pos);
+      if (t2 == BS_GEOM_CAPSULE) {  // cap centre +axis, then -axis
+        const V3 w = mrot(b.R, V3{0, 0, sub == 0 ? b.size.y : -b.size.y});
+        hit = plane_point(pp, n, V3{b.xpos.x + w.x, b.xpos.y + w.y, b.xpos.z + w.z}, b.size.x, margin, dist, pos);
+      } else {
+        // corner `sub`, bit 0 / 1 / 2 set = positive x / y / z side (mjc_PlaneBox's order [EXT]): a contact when the
+        // corner is on the plane's side of the box centre and below the margin, and fewer than four before it were
+        int before = 0;
+        bool mine = false;
+        V3 cs = {0, 0, 0};
+        for (int j = 0; j <= sub; j++) {
+          const V3 o = mrot(b.R, V3{j & 1 ? b.size.x : -b.size.x, j & 2 ? b.size.y : -b.size.y, j & 4 ? b.size.z : -b.size.z});
+          const V3 cj = {b.xpos.x + o.x, b.xpos.y + o.y, b.xpos.z + o.z};
+          const bool ok = !(dot(sub3(cj, pp), n) > margin) && !(dot(n, o) > 0);
+          if (j < sub) before += ok;
+          else { mine = ok; cs = cj; }
+        }
+        hit = mine && before < 4 && plane_point(pp, n, cs, 0.0, margin, dist, pos);
+      }
       nrm = n;
       done = true;
     } else if (t1 == BS_GEOM_SPHERE || (t1 == BS_GEOM_CAPSULE && t2 == BS_GEOM_CAPSULE)) {
@@ -771,9 +818,7 @@ __device__ inline void col_narrowphase(const ColModel& cm, const DevData& d, con
         done = true;
       } else if (t1 == BS_GEOM_CAPSULE) {
         const V3 a1 = {AT(c.geom_xmat, 9 * g1 + 2), AT(c.geom_xmat, 9 * g1 + 5), AT(c.geom_xmat, 9 * g1 + 8)};
-        V3 p1, p2;
-        seg_seg_closest(x1, a1, s1.y, b.xpos, a2, b.size.y, p1, p2);
-        hit = sphere_sphere(p1, s1.x, p2, b.size.x, margin, dist, pos, nrm);
+        hit = capsule_capsule(x1, a1, s1.y, s1.x, b.xpos, a2, b.size.y, b.size.x, margin, sub, dist, pos, nrm);
         done = true;
       }
     }

@@ -13,8 +13,10 @@
  *   - plane-mesh (the build's own ground plane): deepest hull vertex;
  *   - primitive geoms (north_star "plus plane/primitive pairs"; the dialect's geom default is mesh,
  *     src/Mujoco_XML.py:70, primitives only appear when a user edits it): closed forms for
- *     plane-sphere / plane-capsule (2 contacts) / plane-box (one per corner below the margin),
- *     sphere-sphere, sphere-capsule, capsule-capsule (closest points of the segments, ONE contact);
+ *     plane-sphere / plane-capsule (2 contacts) / plane-box (mjc_PlaneBox's rule [EXT]: corners on the plane's side of
+ *     the box centre and below the margin, the first four in corner order),
+ *     sphere-sphere, sphere-capsule, capsule-capsule (closest points of the segments; parallel axes: up to two,
+ *     at the ends of the overlap, as mjc_CapsuleCapsule [EXT]);
  *     every other convex pair (box, cylinder, ellipsoid, mesh in any combination, sphere-box,
  *     capsule-box) goes through the same MPR with the primitives' support functions — MuJoCo's
  *     native box-box / capsule-box routines return more contacts per pair [EXT], this returns one;
@@ -433,11 +435,47 @@ static void seg_seg_closest(const double *c1, const double *a1, double h1, const
   for (int k = 0; k < 3; k++) { p1[k] = c1[k] + t1 * a1[k]; p2[k] = c2[k] + t2 * a2[k]; }
 }
 
+/* capsule - capsule, sub-contact `sub` (mjc_CapsuleCapsule's shape [EXT]): axes in general position give ONE contact
+ * between the closest points of the two segments; (near-)parallel axes give up to TWO — the end points of each
+ * segment against the closest point of the other one, tested in the order +end / -end of capsule 1, then of capsule 2,
+ * until two have been found — so that a capsule resting on a parallel one is supported at both ends of the overlap */
+static int capsule_capsule(const double *c1, const double *a1, double h1, double r1, const double *c2, const double *a2,
+                           double h2, double r2, double margin, int sub, double *dist, double *pos, double *normal) {
+  double w[3];
+  sub3(w, c1, c2);
+  double b = dot3(a1, a2), d1 = dot3(a1, w), d2 = dot3(a2, w), den = 1 - b * b;
+  if (den > 1e-12) {
+    if (sub != 0) return 0;
+    double p1[3], p2[3];
+    seg_seg_closest(c1, a1, h1, c2, a2, h2, p1, p2);
+    return sphere_sphere(p1, r1, p2, r2, margin, dist, pos, normal);
+  }
+  int found = 0;
+  for (int k = 0; k < 4 && found < 2; k++) {
+    double t1, t2, p1[3], p2[3];
+    if (k < 2) { /* an end of segment 1 and the point of segment 2 closest to it */
+      t1 = k == 0 ? h1 : -h1;
+      t2 = d2 + b * t1;
+      t2 = t2 > h2 ? h2 : (t2 < -h2 ? -h2 : t2);
+    } else { /* an end of segment 2 and the point of segment 1 closest to it */
+      t2 = k == 2 ? h2 : -h2;
+      t1 = b * t2 - d1;
+      t1 = t1 > h1 ? h1 : (t1 < -h1 ? -h1 : t1);
+    }
+    for (int q = 0; q < 3; q++) { p1[q] = c1[q] + t1 * a1[q]; p2[q] = c2[q] + t2 * a2[q]; }
+    if (!sphere_sphere(p1, r1, p2, r2, margin, dist, pos, normal)) continue;
+    if (found == sub) return 1;
+    found++;
+  }
+  return 0;
+}
+
 /* contacts a candidate pair can produce (sub-contacts are numbered 0 .. n-1) */
 int orc_pair_nsub(const orc_model *m, int g1, int g2) {
   int t1 = m->geom_type[g1], t2 = m->geom_type[g2];
   if (t1 == GEOM_PLANE && t2 == GEOM_CAPSULE) return 2;
   if (t1 == GEOM_PLANE && t2 == GEOM_BOX) return 8;
+  if (t1 == GEOM_CAPSULE && t2 == GEOM_CAPSULE) return 2;
   return 1;
 }
 /* sub-contact `sub` of the pair (g1, g2): 1 when it exists.  Counts MPR work in iters / npair. */
@@ -453,10 +491,24 @@ static int narrow_sub(const orc_model *m, const orc_data *d, int g1, int g2, int
       double sg = sub == 0 ? s2[1] : -s2[1], c[3] = {x2[0] + sg * R2[2], x2[1] + sg * R2[5], x2[2] + sg * R2[8]};
       return plane_point(d, g1, c, s2[0], margin, dist, pos, normal);
     }
-    if (t2 == GEOM_BOX) { /* corner `sub`: bit 0 / 1 / 2 set = negative x / y / z side */
-      double v[3] = {sub & 1 ? -s2[0] : s2[0], sub & 2 ? -s2[1] : s2[1], sub & 4 ? -s2[2] : s2[2]}, c[3];
-      for (int r = 0; r < 3; r++) c[r] = x2[r] + R2[3 * r] * v[0] + R2[3 * r + 1] * v[1] + R2[3 * r + 2] * v[2];
-      return plane_point(d, g1, c, 0.0, margin, dist, pos, normal);
+    if (t2 == GEOM_BOX) {
+      /* corner `sub`: bit 0 / 1 / 2 set = positive x / y / z side (mjc_PlaneBox's corner order [EXT]).  A corner
+       * makes a contact when it is on the plane's side of the box centre (ldist <= 0) and below the margin, and
+       * fewer than four corners before it did: MuJoCo stops at four */
+      const double *pm = d->geom_xmat + 9 * g1, *pp = d->geom_xpos + 3 * g1;
+      double n[3] = {pm[2], pm[5], pm[8]};
+      int before = 0, mine = 0;
+      double cs[3] = {0, 0, 0};
+      for (int j = 0; j <= sub; j++) {
+        double v[3] = {j & 1 ? s2[0] : -s2[0], j & 2 ? s2[1] : -s2[1], j & 4 ? s2[2] : -s2[2]}, o[3], c[3], df[3];
+        for (int r = 0; r < 3; r++) { o[r] = R2[3 * r] * v[0] + R2[3 * r + 1] * v[1] + R2[3 * r + 2] * v[2]; c[r] = x2[r] + o[r]; }
+        sub3(df, c, pp);
+        int ok = !(dot3(df, n) > margin) && !(dot3(n, o) > 0);
+        if (j < sub) before += ok;
+        else { mine = ok; memcpy(cs, c, 24); }
+      }
+      if (!mine || before >= 4) return 0;
+      return plane_point(d, g1, cs, 0.0, margin, dist, pos, normal);
     }
     return plane_pair(m, d, g1, g2, margin, dist, pos, normal);
   }
@@ -467,9 +519,8 @@ static int narrow_sub(const orc_model *m, const orc_data *d, int g1, int g2, int
     return sphere_sphere(x1, s1[0], p, s2[0], margin, dist, pos, normal);
   }
   if (t1 == GEOM_CAPSULE && t2 == GEOM_CAPSULE) {
-    double a1[3] = {R1[2], R1[5], R1[8]}, a2[3] = {R2[2], R2[5], R2[8]}, p1[3], p2[3];
-    seg_seg_closest(x1, a1, s1[1], x2, a2, s2[1], p1, p2);
-    return sphere_sphere(p1, s1[0], p2, s2[0], margin, dist, pos, normal);
+    double a1[3] = {R1[2], R1[5], R1[8]}, a2[3] = {R2[2], R2[5], R2[8]};
+    return capsule_capsule(x1, a1, s1[1], s1[0], x2, a2, s2[1], s2[0], margin, sub, dist, pos, normal);
   }
   (*npair)++;
   return convex_pair(m, d, g1, g2, margin, dist, pos, normal, iters);

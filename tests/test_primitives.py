@@ -72,6 +72,68 @@ def test_sphere_sphere_capsule_closed_forms():
     assert abs(c[2] - (0.08 - 0.09)) < 1e-15 and np.allclose(c[4], [0, 0, 1]) and np.allclose(c[3], [0, 0, 3.0 + 0.05 - 0.005])
 
 
+_ALONG_X = 'quat="0.7071067811865476 0 0.7071067811865476 0"'
+
+
+def _parallel_model():
+    """Two capsules along x, one resting 0.08 above the other and shifted by 0.15, and a box whose margin (0.5)
+    reaches above its upper corners: the two cases where MuJoCo's native routines count contacts differently from
+    'one per closest point' / 'one per corner below the margin' (mjc_CapsuleCapsule, mjc_PlaneBox [EXT])."""
+    return mujoco_amd.load_model_from_xml(_xml(
+        _slider("lo", f'type="capsule" size="0.05 0.3" {_ALONG_X}', x=0.0, z=3.0)
+        + _slider("hi", f'type="capsule" size="0.04 0.2" {_ALONG_X}', x=0.15, z=3.08)
+        + _slider("box", 'type="box" size="0.1 0.2 0.3" margin="0.5"', x=2.0, z=0.35)))
+
+
+def test_parallel_capsules_two_contacts_and_plane_box_four():
+    m = _parallel_model()
+    gid = m.geom_name2id
+    s = OracleSim(m)
+    s.forward()
+    con = _contacts(s)
+    # segment 1 spans x in [-0.3, 0.3], segment 2 [-0.05, 0.35]: its +end (x = 0.3) and segment 2's -end (x = -0.05)
+    # are 0.08 apart from the other axis (-0.01 after the radii); the other two ends are out of reach
+    cc = [c for c in con if (c[0], c[1]) == (gid("lo_g"), gid("hi_g"))]
+    assert len(cc) == 2
+    assert [round(c[3][0], 9) for c in cc] == [0.3, -0.05]           # MuJoCo's order: ends of capsule 1, then of capsule 2
+    for c in cc:
+        assert abs(c[2] - (0.08 - 0.09)) < 1e-12 and np.allclose(c[4], [0, 0, 1], atol=1e-12)
+        assert abs(c[3][2] - (3.0 + 0.05 - 0.005)) < 1e-12
+    # the box: all 8 corners are below the margin (0.05 and 0.65 < 0.5 + ... no: 0.65 > 0.5), so take a closer look:
+    # lower corners at 0.05 (contacts), upper corners at 0.65 (above the margin AND on the far side of the centre)
+    box = [c for c in con if c[1] == gid("box_g")]
+    assert len(box) == 4 and all(abs(c[2] - 0.05) < 1e-12 for c in box)
+    assert [(round(c[3][0] - 2.0, 9), round(c[3][1], 9)) for c in box] == [(-0.1, -0.2), (0.1, -0.2), (-0.1, 0.2), (0.1, 0.2)]
+    # lowered until the upper corners are below the margin too: still the four on the plane's side of the centre
+    s.qpos[2] = -0.2   # centre 0.15: lower corners at -0.15, upper at 0.45 < 0.5
+    s.forward()
+    box = [c for c in _contacts(s) if c[1] == gid("box_g")]
+    assert len(box) == 4 and all(abs(c[2] - (-0.15)) < 1e-12 for c in box)
+    # capsules a hair off parallel take the general branch: one contact, between the closest points
+    c, cz, sz = float(np.sqrt(0.5)), float(np.cos(0.005)), float(np.sin(0.005))     # yaw of 0.01 rad after the pitch that lays the axis along x
+    s2 = OracleSim(mujoco_amd.load_model_from_xml(_xml(
+        _slider("lo", f'type="capsule" size="0.05 0.3" {_ALONG_X}', x=0.0, z=3.0)
+        + _slider("hi", f'type="capsule" size="0.04 0.2" quat="{cz * c!r} {-sz * c!r} {cz * c!r} {sz * c!r}"', x=0.15, z=3.08))))
+    s2.forward()
+    assert s2.ncon == 1 and abs(s2.contacts()[0]["dist"] - (-0.01)) < 1e-12
+
+
+def test_parallel_capsule_rests_on_both_contacts():
+    """A capsule dropped on a parallel fixed one stays level: with a single contact at a segment end it would tip."""
+    m = mujoco_amd.load_model_from_xml(_xml(
+        '<body name="lift" pos="0.1 0 0.181"><joint name="lift_z" type="slide" axis="0 0 1"/>'
+        '<geom name="lift_g" type="sphere" size="0.01" contype="0" conaffinity="0"/>'
+        '<body name="hi" pos="0 0 0"><joint name="pitch" type="hinge" axis="0 1 0"/>'
+        f'<geom name="hi_g" type="capsule" size="0.04 0.2" {_ALONG_X}/></body></body>',
+        extra=f'<geom name="lo_g" type="capsule" size="0.05 0.4" pos="0 0 0.05" {_ALONG_X}/>'))
+    s = OracleSim(m)
+    s.step(300)
+    cc = [c for c in s.contacts() if c["geom2"] == m.geom_name2id("hi_g")]
+    assert len(cc) == 2 and s.warning == 0
+    assert abs(s.qpos[0] - (0.14 - 0.181)) < 2e-3   # resting on top: 0.05 + 0.05 + 0.04
+    assert abs(s.qpos[1]) < 1e-3                     # level
+
+
 def test_box_box_and_mixed_convex_pairs_by_mpr():
     """Convex pairs without a closed form go through MPR with the primitives' support functions:
     face-to-face boxes (depth known), sphere in a box corner region, capsule on a box, cylinder, ellipsoid."""
@@ -187,3 +249,47 @@ def test_primitive_pairs_device_vs_oracle(kernel, monkeypatch):
         s.qpos[:] = q[e]
         s.step(50)
         assert np.abs(qg[e] - s.qpos).max() < 5e-3, e
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kernel", ["tp", "serial"])
+def test_parallel_capsules_and_margin_box_device_vs_oracle(kernel, monkeypatch):
+    """The two contact-count rules taken from MuJoCo's native routines (parallel capsule-capsule: up to 2; plane-box:
+    the corners on the plane's side of the centre, at most 4), device vs oracle: same lists in the same order."""
+    import torch
+    from mujoco_amd import BatchSim
+    monkeypatch.setenv("BS_KERNEL", kernel)
+    m = _parallel_model()
+    E = 48
+    rng = np.random.default_rng(11)
+    q = np.zeros((E, m.nq))
+    q[:, 0] = rng.uniform(-0.02, 0.02, size=E)
+    q[:, 1] = rng.uniform(-0.02, 0.02, size=E)
+    q[:, 2] = rng.uniform(-0.3, 0.3, size=E)
+    sim = BatchSim(m, n_envs=E)
+    monkeypatch.delenv("BS_KERNEL")
+    sim.data.qpos.copy_(torch.as_tensor(q))
+    sim.forward(); sim.sync()
+    assert int((sim.data.warning != 0).sum()) == 0
+    qacc = sim.data.qacc.cpu().numpy()
+    two = four = 0
+    for e in range(E):
+        s = OracleSim(m)
+        s.qpos[:] = q[e]
+        s.forward()
+        got = sim.data.contact_list(e)
+        assert [(c.geom1, c.geom2) for c in got] == [(c["geom1"], c["geom2"]) for c in s.contacts()], e
+        for a, b in zip(got, s.contacts()):
+            assert abs(a.dist - b["dist"]) < 1e-12 and np.abs(a.pos - b["pos"]).max() < 1e-12, e
+            assert np.abs(a.frame - b["frame"]).max() < 1e-12, e
+        two += sum(1 for c in got if m.geom_type[c.geom1] == 3) == 2
+        four += sum(1 for c in got if m.geom_type[c.geom2] == 6) == 4
+        assert np.abs(qacc[e] - s.qacc).max() / max(1.0, np.abs(s.qacc).max()) < 1e-8, e
+    assert two >= 10 and four >= 10
+    sim.step(100); sim.sync()
+    qg = sim.data.qpos.cpu().numpy()
+    for e in (0, 17, 47):
+        s = OracleSim(m)
+        s.qpos[:] = q[e]
+        s.step(100)
+        assert np.abs(qg[e] - s.qpos).max() < 1e-7, e
