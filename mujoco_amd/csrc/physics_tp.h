@@ -363,13 +363,15 @@ __device__ __forceinline__ int tp_child_w(int w, int ch) { return ((w >> ((ch - 
 // after its parent dof's, single-child chains numbered depth-first) — a DPP wavefront shift, which keeps the
 // sweeps' packets off the CU's LDS pipe.  Compile-time per level: a run-time choice doubled the sweeps' code and
 // register pressure (scratch 96 -> 280 B) and lost more than the shifts won.
-__device__ __forceinline__ double tp_up(double x, int sa, bool shift, bool recv) {
-  if (shift) {  // constant once the level loop is unrolled
-    const double v = dpp_mov<0x130>(x);  // wave_shl:1: lane l reads lane l + 1
-    return recv ? v : 0.0;
-  }
+// A shifted value arrives on EVERY lane (whatever the next lane holds: a finite packet, see below); the lanes it is
+// not meant for take it with the factor rm = 0, the receiving lane with rm = 1 — tp_add / tp_sub: one FMA (exact:
+// v * 1 + acc rounds once, like acc + v) where a select of v cost two v_cndmask in front of the add.
+__device__ __forceinline__ double tp_up(double x, int sa, bool shift) {
+  if (shift) return dpp_mov<0x130>(x);  // wave_shl:1: lane l reads lane l + 1 (shift: constant once the level loop is unrolled)
   return bperm(x, sa);
 }
+__device__ __forceinline__ double tp_add(double acc, double v, double rm, bool shift) { return shift ? __builtin_fma(v, rm, acc) : acc + v; }
+__device__ __forceinline__ double tp_sub(double acc, double v, double rm, bool shift) { return shift ? __builtin_fma(-v, rm, acc) : acc - v; }
 // The packets a level sends (T, S, U below) carry NO sender-side select: a receiver reads either its child — a
 // lane of the level that sends — or the environment's zero lane, whose rows, accumulators and right-hand side are
 // exact zeros and so are the packets it forms; what the other lanes compute at a level that is not theirs is never
@@ -401,12 +403,11 @@ __device__ TP_HELPER_ATTR TpFac tp_factor(TpCtx c, TpRow Rin) {
         if (b >= D) continue;
         T[pair_idx(a, b)] = tmp * R[b] + A[pair_idx(a, b)];
       }
-      if (is) R[a] = tmp;
     }
     if (is) dinv = ir0;
     if (D == 1) break;
     const bool par = c.dd == D - 1;
-    const bool recv = par && c.dchild0 == c.self_sa + 4;  // CHAIN: the child dof is on the next lane
+    const double rm = par && c.dchild0 == c.self_sa + 4 ? 1.0 : 0.0;  // CHAIN: the child dof is on the next lane
     auto round = [&](int ch) {
       const int src = ch == 0 ? c.dchild0 : (CHAIN && D == 2 ? tp_child_w(c.dchild_w, ch) : tp_child(c.tbl, TPL_DCHILD, ch));
       const int sa = par ? src : c.zero_sa;
@@ -416,9 +417,9 @@ __device__ TP_HELPER_ATTR TpFac tp_factor(TpCtx c, TpRow Rin) {
 #pragma unroll
         for (int b = a; b < TP_MAXD; b++) {
           if (b >= D) continue;
-          const double v = tp_up(T[pair_idx(a, b)], sa, CHAIN && D >= 3, recv);
-          if (a == 1) R[b - 1] -= v;
-          else A[pair_idx(a - 1, b - 1)] += v;
+          const double v = tp_up(T[pair_idx(a, b)], sa, CHAIN && D >= 3);
+          if (a == 1) R[b - 1] = tp_sub(R[b - 1], v, rm, CHAIN && D >= 3);
+          else A[pair_idx(a - 1, b - 1)] = tp_add(A[pair_idx(a - 1, b - 1)], v, rm, CHAIN && D >= 3);
         }
       }
     };
@@ -430,11 +431,36 @@ __device__ TP_HELPER_ATTR TpFac tp_factor(TpCtx c, TpRow Rin) {
       for (int ch = 0; ch < (CHAIN && D >= 3 ? 1 : c.nchild[D]); ch++) round(ch);
     }
   }
+  // L(k, a) = M(k, a) / d(k): the row is final from the lane's own level on (nothing is received after it), so it is
+  // scaled once here with the pivot's reciprocal of that level — the same product the level formed as tmp
   TpFac out;
+  out.R.r[0] = R[0];
 #pragma unroll
-  for (int a = 0; a < TP_MAXD; a++) out.R.r[a] = R[a];
+  for (int a = 1; a < TP_MAXD; a++) out.R.r[a] = R[a] * dinv;
   out.dinv = dinv;
   return out;
+}
+
+// root-to-leaves half of a solve: x(k) -= sum over the ancestors a of L(k, a) x(a), level by level from the root.
+// Every lane forms the update of every level (what it fetches at a level that is not its own is finite and dropped)
+// and the lanes of the level keep it: one select per level instead of one per term, same order of rounding.
+template <bool CHAIN>
+__device__ __forceinline__ double tp_back(const TpCtx& c, const double* R, double x) {
+#pragma unroll
+  for (int D = 2; D <= TP_MAXD; D++) {
+    if (D > c.maxdd) continue;
+    double xs = x, xn = x;  // CHAIN: xs = x of the lane a places below (the ancestors of a chain dof, up to the first branching)
+#pragma unroll
+    for (int a = 1; a < TP_MAXD; a++) {
+      if (a >= D) continue;
+      double xa;
+      if (CHAIN && a <= D - 2) { xs = dpp_mov<0x138>(xs); xa = xs; }  // wave_shr:1
+      else xa = bperm(x, CHAIN ? c.top_sa : c.anc_sa[a]);  // CHAIN: a == D - 1, the dof above the chain
+      xn -= R[a] * xa;
+    }
+    if (c.dd == D) x = xn;
+  }
+  return x;
 }
 
 // tp_factor followed by tp_solve with the same matrix, in one leaves-to-root pass: when the rows of
@@ -464,28 +490,27 @@ __device__ TP_HELPER_ATTR double tp_factor_solve(TpCtx c, TpRow Rin, double x) {
         if (b >= D) continue;
         T[pair_idx(a, b)] = tmp * R[b] + A[pair_idx(a, b)];
       }
-      if (is) R[a] = tmp;
       S[a] = tmp * x + W[a];
     }
     if (is) dinv = ir0;
     if (D == 1) break;
     const bool par = c.dd == D - 1;
-    const bool recv = par && c.dchild0 == c.self_sa + 4;  // CHAIN: the child dof is on the next lane
+    const double rm = par && c.dchild0 == c.self_sa + 4 ? 1.0 : 0.0;  // CHAIN: the child dof is on the next lane
     auto round = [&](int ch) {
       const int src = ch == 0 ? c.dchild0 : (CHAIN && D == 2 ? tp_child_w(c.dchild_w, ch) : tp_child(c.tbl, TPL_DCHILD, ch));
       const int sa = par ? src : c.zero_sa;
 #pragma unroll
       for (int a = 1; a < TP_MAXD; a++) {
         if (a >= D) continue;
-        const double sv = tp_up(S[a], sa, CHAIN && D >= 3, recv);
-        if (a == 1) x -= sv;
-        else W[a - 1] += sv;
+        const double sv = tp_up(S[a], sa, CHAIN && D >= 3);
+        if (a == 1) x = tp_sub(x, sv, rm, CHAIN && D >= 3);
+        else W[a - 1] = tp_add(W[a - 1], sv, rm, CHAIN && D >= 3);
 #pragma unroll
         for (int b = a; b < TP_MAXD; b++) {
           if (b >= D) continue;
-          const double v = tp_up(T[pair_idx(a, b)], sa, CHAIN && D >= 3, recv);
-          if (a == 1) R[b - 1] -= v;
-          else A[pair_idx(a - 1, b - 1)] += v;
+          const double v = tp_up(T[pair_idx(a, b)], sa, CHAIN && D >= 3);
+          if (a == 1) R[b - 1] = tp_sub(R[b - 1], v, rm, CHAIN && D >= 3);
+          else A[pair_idx(a - 1, b - 1)] = tp_add(A[pair_idx(a - 1, b - 1)], v, rm, CHAIN && D >= 3);
         }
       }
     };
@@ -497,22 +522,10 @@ __device__ TP_HELPER_ATTR double tp_factor_solve(TpCtx c, TpRow Rin, double x) {
       for (int ch = 0; ch < (CHAIN && D >= 3 ? 1 : c.nchild[D]); ch++) round(ch);
     }
   }
+#pragma unroll
+  for (int a = 1; a < TP_MAXD; a++) R[a] *= dinv;  // as in tp_factor: the row scaled once, after its level
   x *= dinv;
-#pragma unroll
-  for (int D = 2; D <= TP_MAXD; D++) {
-    if (D > c.maxdd) continue;
-    const bool is = c.dd == D;
-    double xs = x;  // CHAIN: x of the lane a places below (the ancestors of a chain dof, up to the first branching)
-#pragma unroll
-    for (int a = 1; a < TP_MAXD; a++) {
-      if (a >= D) continue;
-      double xa;
-      if (CHAIN && a <= D - 2) { xs = dpp_mov<0x138>(xs); xa = xs; }  // wave_shr:1
-      else xa = bperm(x, CHAIN ? c.top_sa : c.anc_sa[a]);  // CHAIN: a == D - 1, the dof above the chain
-      if (is) x -= R[a] * xa;
-    }
-  }
-  return x;
+  return tp_back<CHAIN>(c, R, x);
 }
 
 // two factorisations with the same sparsity at once (M and M + h * damping): the level loop and its
@@ -544,13 +557,12 @@ __device__ TP_HELPER_ATTR void tp_factor2(TpCtx c, TpRow R0in, TpRow R1in, TpFac
           if (b >= D) continue;
           T[n][pair_idx(a, b)] = tmp * R[n][b] + A[n][pair_idx(a, b)];
         }
-        if (is) R[n][a] = tmp;
       }
       if (is) dinv[n] = ir0;
     }
     if (D == 1) break;
     const bool par = c.dd == D - 1;
-    const bool recv = par && c.dchild0 == c.self_sa + 4;  // CHAIN: the child dof is on the next lane
+    const double rm = par && c.dchild0 == c.self_sa + 4 ? 1.0 : 0.0;  // CHAIN: the child dof is on the next lane
     auto round = [&](int ch) {
       const int src = ch == 0 ? c.dchild0 : (CHAIN && D == 2 ? tp_child_w(c.dchild_w, ch) : tp_child(c.tbl, TPL_DCHILD, ch));
       const int sa = par ? src : c.zero_sa;
@@ -562,9 +574,9 @@ __device__ TP_HELPER_ATTR void tp_factor2(TpCtx c, TpRow R0in, TpRow R1in, TpFac
           if (b >= D) continue;
 #pragma unroll
           for (int n = 0; n < 2; n++) {
-            const double v = tp_up(T[n][pair_idx(a, b)], sa, CHAIN && D >= 3, recv);
-            if (a == 1) R[n][b - 1] -= v;
-            else A[n][pair_idx(a - 1, b - 1)] += v;
+            const double v = tp_up(T[n][pair_idx(a, b)], sa, CHAIN && D >= 3);
+            if (a == 1) R[n][b - 1] = tp_sub(R[n][b - 1], v, rm, CHAIN && D >= 3);
+            else A[n][pair_idx(a - 1, b - 1)] = tp_add(A[n][pair_idx(a - 1, b - 1)], v, rm, CHAIN && D >= 3);
           }
         }
       }
@@ -577,8 +589,9 @@ __device__ TP_HELPER_ATTR void tp_factor2(TpCtx c, TpRow R0in, TpRow R1in, TpFac
       for (int ch = 0; ch < (CHAIN && D >= 3 ? 1 : c.nchild[D]); ch++) round(ch);
     }
   }
+  out0.R.r[0] = R[0][0]; out1.R.r[0] = R[1][0];
 #pragma unroll
-  for (int a = 0; a < TP_MAXD; a++) { out0.R.r[a] = R[0][a]; out1.R.r[a] = R[1][a]; }
+  for (int a = 1; a < TP_MAXD; a++) { out0.R.r[a] = R[0][a] * dinv[0]; out1.R.r[a] = R[1][a] * dinv[1]; }
   out0.dinv = dinv[0]; out1.dinv = dinv[1];
 }
 
@@ -593,7 +606,7 @@ __device__ TP_HELPER_ATTR double tp_solve(TpCtx c, TpRow Rin, double dinv, doubl
   for (int D = TP_MAXD; D >= 2; D--) {
     if (D > c.maxdd) continue;
     const bool par = c.dd == D - 1;
-    const bool recv = par && c.dchild0 == c.self_sa + 4;  // CHAIN: the child dof is on the next lane
+    const double rm = par && c.dchild0 == c.self_sa + 4 ? 1.0 : 0.0;  // CHAIN: the child dof is on the next lane
     double T[TP_MAXD];
 #pragma unroll
     for (int a = 1; a < TP_MAXD; a++)
@@ -604,9 +617,9 @@ __device__ TP_HELPER_ATTR double tp_solve(TpCtx c, TpRow Rin, double dinv, doubl
 #pragma unroll
       for (int a = 1; a < TP_MAXD; a++) {
         if (a >= D) continue;
-        const double v = tp_up(T[a], sa, CHAIN && D >= 3, recv);
-        if (a == 1) x -= v;
-        else W[a - 1] += v;
+        const double v = tp_up(T[a], sa, CHAIN && D >= 3);
+        if (a == 1) x = tp_sub(x, v, rm, CHAIN && D >= 3);
+        else W[a - 1] = tp_add(W[a - 1], v, rm, CHAIN && D >= 3);
       }
     };
     if (CHAIN && D == 2) {  // the branching level: every child's fetch issued before the first accumulation (table
@@ -618,21 +631,7 @@ __device__ TP_HELPER_ATTR double tp_solve(TpCtx c, TpRow Rin, double dinv, doubl
     }
   }
   x *= dinv;
-#pragma unroll
-  for (int D = 2; D <= TP_MAXD; D++) {
-    if (D > c.maxdd) continue;
-    const bool is = c.dd == D;
-    double xs = x;  // CHAIN: x of the lane a places below (the ancestors of a chain dof, up to the first branching)
-#pragma unroll
-    for (int a = 1; a < TP_MAXD; a++) {
-      if (a >= D) continue;
-      double xa;
-      if (CHAIN && a <= D - 2) { xs = dpp_mov<0x138>(xs); xa = xs; }  // wave_shr:1
-      else xa = bperm(x, CHAIN ? c.top_sa : c.anc_sa[a]);  // CHAIN: a == D - 1, the dof above the chain
-      if (is) x -= R[a] * xa;
-    }
-  }
-  return x;
+  return tp_back<CHAIN>(c, R, x);
 }
 
 // tp_solve(R, dinv, x) and tp_mul_m(M, v) in one pass: the leaves-to-root sweeps of the two have the
@@ -663,7 +662,7 @@ __device__ TP_HELPER_ATTR double tp_solve_mulm(TpCtx c, TpRow Rin, double dinv, 
   for (int D = TP_MAXD; D >= 2; D--) {
     if (D > c.maxdd) continue;
     const bool par = c.dd == D - 1;
-    const bool recv = par && c.dchild0 == c.self_sa + 4;  // CHAIN: the child dof is on the next lane
+    const double rm = par && c.dchild0 == c.self_sa + 4 ? 1.0 : 0.0;  // CHAIN: the child dof is on the next lane
     double T[TP_MAXD], U[TP_MAXD];
 #pragma unroll
     for (int a = 1; a < TP_MAXD; a++)
@@ -674,9 +673,9 @@ __device__ TP_HELPER_ATTR double tp_solve_mulm(TpCtx c, TpRow Rin, double dinv, 
 #pragma unroll
       for (int a = 1; a < TP_MAXD; a++) {
         if (a >= D) continue;
-        const double t = tp_up(T[a], sa, CHAIN && D >= 3, recv), u = tp_up(U[a], sa, CHAIN && D >= 3, recv);
-        if (a == 1) { x -= t; res += u; }
-        else { W[a - 1] += t; V[a - 1] += u; }
+        const double t = tp_up(T[a], sa, CHAIN && D >= 3), u = tp_up(U[a], sa, CHAIN && D >= 3);
+        if (a == 1) { x = tp_sub(x, t, rm, CHAIN && D >= 3); res = tp_add(res, u, rm, CHAIN && D >= 3); }
+        else { W[a - 1] = tp_add(W[a - 1], t, rm, CHAIN && D >= 3); V[a - 1] = tp_add(V[a - 1], u, rm, CHAIN && D >= 3); }
       }
     };
     if (CHAIN && D == 2) {  // the branching level: every child's fetch issued before the first accumulation (table
@@ -689,21 +688,7 @@ __device__ TP_HELPER_ATTR double tp_solve_mulm(TpCtx c, TpRow Rin, double dinv, 
   }
   mv = res;
   x *= dinv;
-#pragma unroll
-  for (int D = 2; D <= TP_MAXD; D++) {
-    if (D > c.maxdd) continue;
-    const bool is = c.dd == D;
-    double xs = x;  // CHAIN: x of the lane a places below (the ancestors of a chain dof, up to the first branching)
-#pragma unroll
-    for (int a = 1; a < TP_MAXD; a++) {
-      if (a >= D) continue;
-      double xa;
-      if (CHAIN && a <= D - 2) { xs = dpp_mov<0x138>(xs); xa = xs; }  // wave_shr:1
-      else xa = bperm(x, CHAIN ? c.top_sa : c.anc_sa[a]);  // CHAIN: a == D - 1, the dof above the chain
-      if (is) x -= R[a] * xa;
-    }
-  }
-  return x;
+  return tp_back<CHAIN>(c, R, x);
 }
 
 // N right-hand sides at once: the level sweeps and their cross-lane round trips are shared
@@ -719,7 +704,7 @@ __device__ TP_HELPER_ATTR void tp_solve_n(TpCtx c, TpRow Rin, double dinv, doubl
   for (int D = TP_MAXD; D >= 2; D--) {
     if (D > c.maxdd) continue;
     const bool par = c.dd == D - 1;
-    const bool recv = par && c.dchild0 == c.self_sa + 4;  // CHAIN: the child dof is on the next lane
+    const double rm = par && c.dchild0 == c.self_sa + 4 ? 1.0 : 0.0;  // CHAIN: the child dof is on the next lane
     double T[N][TP_MAXD];
 #pragma unroll
     for (int n = 0; n < N; n++)
@@ -734,9 +719,9 @@ __device__ TP_HELPER_ATTR void tp_solve_n(TpCtx c, TpRow Rin, double dinv, doubl
         if (a >= D) continue;
 #pragma unroll
         for (int n = 0; n < N; n++) {
-          const double v = tp_up(T[n][a], sa, CHAIN && D >= 3, recv);
-          if (a == 1) x[n] -= v;
-          else W[n][a - 1] += v;
+          const double v = tp_up(T[n][a], sa, CHAIN && D >= 3);
+          if (a == 1) x[n] = tp_sub(x[n], v, rm, CHAIN && D >= 3);
+          else W[n][a - 1] = tp_add(W[n][a - 1], v, rm, CHAIN && D >= 3);
         }
       }
     };
@@ -753,16 +738,18 @@ __device__ TP_HELPER_ATTR void tp_solve_n(TpCtx c, TpRow Rin, double dinv, doubl
 #pragma unroll
   for (int D = 2; D <= TP_MAXD; D++) {
     if (D > c.maxdd) continue;
-    const bool is = c.dd == D;
+    double xn[N];
+#pragma unroll
+    for (int n = 0; n < N; n++) xn[n] = x[n];
 #pragma unroll
     for (int a = 1; a < TP_MAXD; a++) {
       if (a >= D) continue;
 #pragma unroll
-      for (int n = 0; n < N; n++) {
-        const double xa = bperm(x[n], c.anc_sa[a]);
-        if (is) x[n] -= R[a] * xa;
-      }
+      for (int n = 0; n < N; n++) xn[n] -= R[a] * bperm(x[n], c.anc_sa[a]);
     }
+    if (c.dd == D)
+#pragma unroll
+      for (int n = 0; n < N; n++) x[n] = xn[n];
   }
 }
 
@@ -792,7 +779,7 @@ __device__ TP_HELPER_ATTR double tp_mul_m(TpCtx c, TpRow Min, double v) {
   for (int D = TP_MAXD; D >= 2; D--) {
     if (D > c.maxdd) continue;
     const bool par = c.dd == D - 1;
-    const bool recv = par && c.dchild0 == c.self_sa + 4;  // CHAIN: the child dof is on the next lane
+    const double rm = par && c.dchild0 == c.self_sa + 4 ? 1.0 : 0.0;  // CHAIN: the child dof is on the next lane
     double T[TP_MAXD];
 #pragma unroll
     for (int a = 1; a < TP_MAXD; a++)
@@ -803,9 +790,9 @@ __device__ TP_HELPER_ATTR double tp_mul_m(TpCtx c, TpRow Min, double v) {
 #pragma unroll
       for (int a = 1; a < TP_MAXD; a++) {
         if (a >= D) continue;
-        const double x = tp_up(T[a], sa, CHAIN && D >= 3, recv);
-        if (a == 1) res += x;
-        else W[a - 1] += x;
+        const double x = tp_up(T[a], sa, CHAIN && D >= 3);
+        if (a == 1) res = tp_add(res, x, rm, CHAIN && D >= 3);
+        else W[a - 1] = tp_add(W[a - 1], x, rm, CHAIN && D >= 3);
       }
     };
     if (CHAIN && D == 2) {  // the branching level: every child's fetch issued before the first accumulation (table
@@ -1451,11 +1438,12 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
           if (t.lvl_next[lvl]) {
             // every body of this level sits on the lane after its parent's (single-child chains numbered depth-first):
             // the parent takes its child's values with a wavefront shift (DPP wave_shl:1), no LDS-pipe instruction
-            const bool recv = par && bchild0 == self_sa + 4;
+            // (taken through the lane's 0 / 1 factor, tp_add: the other lanes' values are finite)
+            const double rm = par && bchild0 == self_sa + 4 ? 1.0 : 0.0;
 #pragma unroll
-            for (int k = 0; k < 10; k++) { const double v = dpp_mov<0x130>(crb[k]); if (recv) crb[k] += v; }
+            for (int k = 0; k < 10; k++) crb[k] = tp_add(crb[k], dpp_mov<0x130>(crb[k]), rm, true);
 #pragma unroll
-            for (int k = 0; k < 6; k++) { const double v = dpp_mov<0x130>(f[k]); if (recv) f[k] += v; }
+            for (int k = 0; k < 6; k++) f[k] = tp_add(f[k], dpp_mov<0x130>(f[k]), rm, true);
             continue;
           }
           for (int ch = 0; ch < t.lvl_bchild[lvl]; ch++) {
@@ -1480,18 +1468,23 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
         double cds[6], cdtop[6];
 #pragma unroll
         for (int k = 0; k < 6; k++) { cds[k] = cdof[k]; cdtop[k] = CHAIN ? bperm(cdof[k], c.top_sa) : 0.0; }
+        double sjtop = 0;
+#pragma unroll
+        for (int k = 0; k < 6; k++) sjtop += cdtop[k] * buf[k];
 #pragma unroll
         for (int a = 1; a < TP_MAXD; a++) {
           Mr.r[a] = 0;
           if (a >= t.maxdd) continue;
           double sj = 0;
           if constexpr (CHAIN) {
-            // the a-th ancestor's motion axis: a lanes below (shifted once more per a), or the top dof's (fetched once)
+            // the a-th ancestor's motion axis: a lanes below (shifted once more per a), or the top dof's (fetched once;
+            // its product sjtop is formed once and selected per a)
 #pragma unroll
             for (int k = 0; k < 6; k++) {
               cds[k] = dpp_mov<0x138>(cds[k]);
-              sj += (a == c.dd - 1 ? cdtop[k] : cds[k]) * buf[k];
+              sj += cds[k] * buf[k];
             }
+            if (a == c.dd - 1) sj = sjtop;
           } else {
 #pragma unroll
             for (int k = 0; k < 6; k++) sj += bperm(cdof[k], c.anc_sa[a]) * buf[k];
