@@ -632,6 +632,49 @@ static int model_image(bs_model* m, int device, const DeviceImage** out) {
   PUT_CI(hull_adj, s.hull_adj, s.nhulladj);
   // climb warm-start table: exhaustive support vertex for the centre direction of every bin
   std::vector<int32_t> hstart((size_t)(s.nmesh > 0 ? s.nmesh : 1) * BS_NSTART, 0);
+  // support candidates: per bin the vertices that are the hull's support vertex for SOME direction of the bin (the
+  // vertices whose normal cone meets the bin's cone of directions).  md_support takes the best of them — no climb,
+  // no verification of the neighbours.  cand[bin] = the list, centre direction's support vertex first.
+  std::vector<std::vector<int32_t>> cand((size_t)(s.nmesh > 0 ? s.nmesh : 1) * BS_NSTART);
+  // does the normal cone of vertex y (directions d with d . (y - n) >= 0 for every neighbour n) meet the bin?  On a
+  // cube face a direction is (s, u, v) up to the order of the components, the bin a rectangle in (u, v) and every
+  // neighbour a half-plane there: the rectangle is clipped by them one after the other.  Tolerances make the answer
+  // err towards "meets" (a candidate too many costs a comparison, one too few a wrong contact).
+  auto cone_meets_bin = [&](int me, int y, int bin) -> bool {
+    const int va = s.mesh_vertadr[me];
+    const double* V = s.hull_vert + 3 * (size_t)va;
+    const int iv = bin % BS_SG, iu = (bin / BS_SG) % BS_SG, face = bin / (BS_SG * BS_SG);
+    const double eps = 1e-9, sg = (face & 1) ? -1.0 : 1.0;
+    const double u0 = ((double)iu / BS_SG - 0.5) * 2 - eps, u1 = ((double)(iu + 1) / BS_SG - 0.5) * 2 + eps;
+    const double v0 = ((double)iv / BS_SG - 0.5) * 2 - eps, v1 = ((double)(iv + 1) / BS_SG - 0.5) * 2 + eps;
+    constexpr int CAP = 96;
+    double pu[CAP] = {u0, u1, u1, u0}, pv[CAP] = {v0, v0, v1, v1}, qu[CAP], qv[CAP];
+    int n = 4;
+    for (int k = s.hull_adj_start[va + y]; k < s.hull_adj_start[va + y + 1]; k++) {
+      const int nb = s.hull_adj[k];
+      const double e[3] = {V[3 * y] - V[3 * nb], V[3 * y + 1] - V[3 * nb + 1], V[3 * y + 2] - V[3 * nb + 2]};
+      double A, B, C;
+      if (face < 2) { C = sg * e[0]; A = e[1]; B = e[2]; }
+      else if (face < 4) { A = e[0]; C = sg * e[1]; B = e[2]; }
+      else { A = e[0]; B = e[1]; C = sg * e[2]; }
+      const double tol = 1e-11 * sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]) + 1e-300;
+      if (n + 2 > CAP) return true;
+      int mq = 0;
+      for (int i = 0; i < n; i++) {
+        const int j = i + 1 < n ? i + 1 : 0;
+        const double fi = A * pu[i] + B * pv[i] + C + tol, fj = A * pu[j] + B * pv[j] + C + tol;
+        if (fi >= 0) { qu[mq] = pu[i]; qv[mq] = pv[i]; mq++; }
+        if ((fi >= 0) != (fj >= 0)) {
+          const double t = fi / (fi - fj);
+          qu[mq] = pu[i] + t * (pu[j] - pu[i]); qv[mq] = pv[i] + t * (pv[j] - pv[i]); mq++;
+        }
+      }
+      if (mq == 0) return false;
+      n = mq;
+      for (int i = 0; i < n; i++) { pu[i] = qu[i]; pv[i] = qv[i]; }
+    }
+    return true;
+  };
   {
     // exhaustive (lowest index wins a tie), 6 x 64 x 64 bins per hull: a few hundred million multiply-adds
     // per model, spread over up to eight host threads
@@ -647,6 +690,17 @@ static int model_image(bs_model* m, int device, const DeviceImage** out) {
           if (val > bv) { bv = val; best = v; }
         }
         hstart[(size_t)me * BS_NSTART + bin] = best;
+        // the vertices of the bin form a connected piece of the hull's graph around `best`: breadth-first from there
+        std::vector<int32_t>& cl = cand[(size_t)me * BS_NSTART + bin];
+        cl.assign(1, best);
+        const int va = s.mesh_vertadr[me];
+        for (size_t at = 0; at < cl.size() && cl.size() < BS_CAND_MAX; at++)
+          for (int k = s.hull_adj_start[va + cl[at]]; k < s.hull_adj_start[va + cl[at] + 1] && cl.size() < BS_CAND_MAX; k++) {
+            const int y = s.hull_adj[k];
+            bool seen = false;
+            for (int32_t z : cl) seen |= z == y;
+            if (!seen && cone_meets_bin(me, y, bin)) cl.push_back(y);
+          }
       }
     };
     unsigned nt = std::thread::hardware_concurrency();
@@ -672,6 +726,28 @@ static int model_image(bs_model* m, int device, const DeviceImage** out) {
       memcpy(r + 3, &bits, sizeof bits);
     }
   fix.push_back({pk.add(start4.data(), start4.size() * sizeof(double)), (void**)&cm.hull_start4});
+  // candidate records: BS_CAND_K per bin {x, y, z, -} (short lists repeat their first vertex), the first one's
+  // fourth word = number of candidates | first record of the rest in hull_more4 << 32
+  std::vector<double> cand4(hstart.size() * 4 * BS_CAND_K, 0.0), more4;
+  for (int me = 0; me < s.nmesh; me++)
+    for (int bin = 0; bin < BS_NSTART; bin++) {
+      const std::vector<int32_t>& cl = cand[(size_t)me * BS_NSTART + bin];
+      const int va = s.mesh_vertadr[me];
+      double* r = &cand4[4 * BS_CAND_K * ((size_t)me * BS_NSTART + bin)];
+      for (int q = 0; q < BS_CAND_K; q++) {
+        const int v = cl[q < (int)cl.size() ? q : 0];
+        for (int k = 0; k < 3; k++) r[4 * q + k] = s.hull_vert[3 * ((size_t)va + v) + k];
+      }
+      const int64_t bits = (int64_t)cl.size() | ((int64_t)(more4.size() / 4) << 32);
+      memcpy(r + 3, &bits, sizeof bits);
+      for (size_t q = BS_CAND_K; q < cl.size(); q++) {
+        for (int k = 0; k < 3; k++) more4.push_back(s.hull_vert[3 * ((size_t)va + cl[q]) + k]);
+        more4.push_back(0.0);
+      }
+    }
+  for (int q = 0; q < 4 * BS_CAND_K; q++) more4.push_back(0.0);  // a clamped read beyond the last list stays inside
+  fix.push_back({pk.add(cand4.data(), cand4.size() * sizeof(double)), (void**)&cm.hull_cand4});
+  fix.push_back({pk.add(more4.data(), more4.size() * sizeof(double)), (void**)&cm.hull_more4});
   // hill-climbing records: neighbour {x, y, z, id} per adjacency entry, padded vertices, ranges
   std::vector<double> nbr4((size_t)(s.nhulladj > 0 ? s.nhulladj : 1) * 4, 0.0);
   std::vector<double> vert4((size_t)(s.nhullvert > 0 ? s.nhullvert : 1) * 4, 0.0);
@@ -911,7 +987,8 @@ static void launch_tpc_pass(bs_sim* s, const DevData& dd, hipStream_t st, int mo
 #endif
   const dim3 g = grid_tp_n(dd.n_envs - dd.env0, s->lpe);
   const size_t nw = (size_t)(64 / s->lpe);  // environments per wavefront
-  const size_t lds_col = nw * s->cm.ngeom * TPG_SLOT * sizeof(double) + nw * s->cm.npair * sizeof(int);  // frames, pair lists
+  const size_t lds_col = nw * s->cm.ngeom * TPG_SLOT * sizeof(double) + nw * s->cm.npair * sizeof(int)  // frames, pair lists,
+                         + nw * 2 * s->cm.maxcand * sizeof(int);                                         // slot records
   (s->wide ? bs_launch_tp_col_w : bs_launch_tp_col)(g, lds_col, st, s->dm, s->tp, dd, s->cm, s->cd);
   if (s->narrow_ws || s->narrow_blocks) {
     launch_narrow(s, dd, st);
@@ -1221,7 +1298,7 @@ extern "C" int bs_sim_create(const bs_model* const* models, int n_models, const 
     const size_t irows = 1 + 1 + mk + 1 + mk;
     const size_t nstat = BS_STAT_CON + BS_NSUB;                        // counters (8 bytes each)
     const size_t nitems = mc * ((size_t)E + 4 * 2 * BS_NSUB);         // narrowphase work list, 4 ranges at most
-    const size_t bytes = drows * E * sizeof(double) + irows * E * sizeof(int) + 16 + nstat * 8 + nitems * sizeof(int);
+    const size_t bytes = drows * E * sizeof(double) + irows * E * sizeof(int) + 16 + nstat * 8 + 16 + nitems * sizeof(int4);
     he = hipMalloc(&s->carena, bytes);
     if (he != hipSuccess) {
     (void)hipGetLastError();  // a failed allocation leaves its error behind: the next call must not trip over it
@@ -1245,7 +1322,7 @@ extern "C" int bs_sim_create(const bs_model* const* models, int n_models, const 
     c.ncon = takei(1); c.con_pair = takei(mk);
     k.ncrow = takei(1); k.con_efc = takei(mk);
     c.stat = (unsigned long long*)(((uintptr_t)ip + 7) & ~(uintptr_t)7);
-    c.items = (int*)(c.stat + nstat);
+    c.items = (int4*)(((uintptr_t)(c.stat + nstat) + 15) & ~(uintptr_t)15);
     s->fields[BS_F_NCON] = {c.ncon, 1, true};
     if (!s->use_tpc) {
       const int rc2 = ensure_serial_contact(s);
@@ -1757,6 +1834,16 @@ extern "C" int bs_collision_stats(bs_sim* s, uint64_t out[3], int reset) {
   }
 #ifdef NP_PROFILE
   bs_np_profile_dump();
+#endif
+#ifdef NP_TIMING
+  {
+    uint64_t t[20];
+    HIPCHK(hipMemcpy(t, s->cd.stat + 8, sizeof t, hipMemcpyDeviceToHost));
+    fprintf(stderr, "np_timing");
+    for (int q = 0; q < 20; q++) fprintf(stderr, " %llu", (unsigned long long)t[q]);
+    fprintf(stderr, "\n");
+    HIPCHK(hipMemset(s->cd.stat + 8, 0, sizeof t));
+  }
 #endif
 #ifdef TPC_PROFILE
   {

@@ -97,7 +97,7 @@ __global__ __launch_bounds__(NL_THREADS, NL_OCC) void k_c_narrow_list(ColModel c
   }
   __syncthreads();
   const unsigned total = pre[BS_NSUB];
-  const int* items = c.items + col_items_base(d.env0, d.range, cm.maxcand);
+  const int4* items = c.items + col_items_base(d.env0, d.range, cm.maxcand);
   unsigned acc[2] = {0, 0};
   if constexpr (!PRIM) {
     // every wavefront owns an equal share of the list and its lanes take items from it as they finish
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(NL_THREADS, NL_OCC) void k_c_narrow_list(ColModel c
         if (pre[mid] <= i) lo = mid;
         else hi = mid;
       }
-      const int it = items[lo * subcap + (i - pre[lo])];
+      const int it = items[lo * subcap + (i - pre[lo])].x;
       col_narrowphase<PRIM>(cm, d, c, d.env0 + (it >> 8), it & 255, acc, mpr[tid]);
     }
   }

@@ -47,6 +47,10 @@ struct ColModel {
   const double4 *hull_nbr4;  // [nhulladj]
   const double4 *hull_start4; // [nmesh][BS_NSTART] record of hull_start's vertex (work-stealing narrowphase)
   const double4 *hull_vert4; // [nhullvert]
+  // support candidates of the persistent narrowphase: per bin the vertices that are the support vertex for SOME
+  // direction of the bin, BS_CAND_K records {x, y, z, -} (first record's w: count | index of the rest in hull_more4 << 32)
+  const double4 *hull_cand4;  // [nmesh][BS_NSTART][BS_CAND_K]
+  const double4 *hull_more4;  // candidates BS_CAND_K.. of the bins that have more
   const int2 *hull_range;    // [nhullvert]
   const double *geom_obb; // [ngeom][6] box around the hull in the geom frame: centre, half extents (< 0: none)
   const double *geom_size; // [ngeom][3] mjModel.geom_size (primitives)
@@ -68,6 +72,8 @@ struct ColModel {
 #define BS_SG 64  // measured at 65 536 envs: 16 -> 28.5, 32 -> 29.3, 48 -> 29.6, 64 -> 29.8 M env-steps/s (climbs start nearer their end;
                   // 19 MB of start records per device for the hand's 24 hulls)
 #define BS_NSTART (6 * BS_SG * BS_SG)
+#define BS_CAND_K 4      // candidate records per bin held in line (98 % of the hand's bins have no more)
+#define BS_CAND_MAX (1 << 20)  // no cap in practice (a flat cap's normal sits in one bin with the cap's whole rim)
 __host__ __device__ inline int dir_bin(double x, double y, double z) {
   const double ax = x < 0 ? -x : x, ay = y < 0 ? -y : y, az = z < 0 ? -z : z;
   int face;
@@ -113,11 +119,12 @@ struct ColData {
   // candidates [maxcand][E]
   int *ncand, *cand_pair, *cand_hit;
   CandRec *crec;  // non-null: candidates live here instead of cand_pair / cand_hit / cand_dist / cand_pos / cand_nrm
-  // narrowphase work list of the tree-parallel path: (env - env0) << 8 | candidate slot.  The
+  // narrowphase work list of the tree-parallel path: {(env - env0) << 8 | candidate slot, pair | sub-contact << 24,
+  // geom1 | geom2 << 16, 0} per item (16 bytes: what the narrowphase's set-up loads depend on, in one load).  The
   // broadphase blocks of a range append to BS_NSUB sub-lists (block index modulo BS_NSUB, so the
   // append counters stat[BS_STAT_ITEMS + range * BS_NSUB + sub] are not one hot address); sub-list
   // s of a range starts at col_items_base() + s * col_items_subcap()
-  int *items;
+  int4 *items;
   double *cand_dist, *cand_pos, *cand_nrm;
   // contacts [maxcon][E]
   int *ncon, *con_pair;
@@ -188,6 +195,7 @@ struct CObj {
   const double4 *vert4, *nbr4, *start4;
   const double4 *vert_all, *start_all;  // the whole tables (uniform) and this mesh's first record in them:
   int vbase, sbase;                     // md_support addresses records with 32-bit offsets from a uniform base
+  const double4 *cand_all, *more_all;   // support candidates per bin (ColModel::hull_cand4 / hull_more4), row sbase + bin
   int cache;
   V3 xpos;
   M3 R;
@@ -254,77 +262,68 @@ __device__ inline V3 hull_support(CObj& o, const V3& dir) {
 __device__ __forceinline__ double4 ld_rec32(const double4* base, int idx) {
   return *(const double4*)((const char*)base + ((unsigned)idx << 5));
 }
-__device__ inline Spt md_support(CObj& a, CObj& b, const V3& dir, bool only_b = false) {
+#ifdef NP_TIMING
+// developer build: wave-level counters of the persistent narrowphase (k_narrow.hip adds them to ColData::stat[8..])
+#define NPT(i, v) { np_t[i] += (unsigned long long)(v); }
+#else
+#define NPT(i, v)
+#endif
+__device__ inline Spt md_support(CObj& a, CObj& b, const V3& dir, bool only_b = false
+#ifdef NP_TIMING
+                                 , unsigned long long* np_t = nullptr
+#endif
+) {
   const V3 da = {a.R.a[0] * dir.x + a.R.a[3] * dir.y + a.R.a[6] * dir.z, a.R.a[1] * dir.x + a.R.a[4] * dir.y + a.R.a[7] * dir.z,
                  a.R.a[2] * dir.x + a.R.a[5] * dir.y + a.R.a[8] * dir.z};
   const V3 nd = neg(dir);
   const V3 db = {b.R.a[0] * nd.x + b.R.a[3] * nd.y + b.R.a[6] * nd.z, b.R.a[1] * nd.x + b.R.a[4] * nd.y + b.R.a[7] * nd.z,
                  b.R.a[2] * nd.x + b.R.a[5] * nd.y + b.R.a[8] * nd.z};
-  // starts of both climbs: better of (previous support vertex, table vertex of the direction bin)
-  const double4 ca = ld_rec32(a.vert_all, a.vbase + a.cache), ta = ld_rec32(a.start_all, a.sbase + dir_bin(da.x, da.y, da.z));
-  const double4 cb = ld_rec32(b.vert_all, b.vbase + b.cache), tb = ld_rec32(b.start_all, b.sbase + dir_bin(db.x, db.y, db.z));
-  V3 best = {ca.x, ca.y, ca.z};
-  double vmax = best.x * da.x + best.y * da.y + best.z * da.z, rec = ca.w;
-  {
-    const double val = ta.x * da.x + ta.y * da.y + ta.z * da.z;
-    if (val > vmax) { vmax = val; rec = ta.w; best = {ta.x, ta.y, ta.z}; }
+  // The support vertex of a hull for direction d is the best of the candidates of d's bin (ColModel::hull_cand4: every
+  // vertex that is the support for some direction of the bin) — one round of loads for both hulls where the hill climb
+  // took three dependent ones (start records, then the neighbours of each hull's start vertex to confirm it).  Bins
+  // with more than BS_CAND_K candidates (2 % of the hand's) continue through their list, both hulls in the same trips.
+  const int ra0 = (a.sbase + dir_bin(da.x, da.y, da.z)) * BS_CAND_K, rb0 = (b.sbase + dir_bin(db.x, db.y, db.z)) * BS_CAND_K;
+  double4 pa[BS_CAND_K], pb[BS_CAND_K];
+#pragma unroll
+  for (int q = 0; q < BS_CAND_K; q++) { pa[q] = ld_rec32(a.cand_all, ra0 + q); pb[q] = ld_rec32(b.cand_all, rb0 + q); }
+  V3 besta = {pa[0].x, pa[0].y, pa[0].z}, bestb = {pb[0].x, pb[0].y, pb[0].z};
+  double vmaxa = besta.x * da.x + besta.y * da.y + besta.z * da.z, vmaxb = bestb.x * db.x + bestb.y * db.y + bestb.z * db.z;
+#pragma unroll
+  for (int q = 1; q < BS_CAND_K; q++) {
+    const double va = pa[q].x * da.x + pa[q].y * da.y + pa[q].z * da.z;
+    if (va > vmaxa) { vmaxa = va; besta = {pa[q].x, pa[q].y, pa[q].z}; }
+    const double vb = pb[q].x * db.x + pb[q].y * db.y + pb[q].z * db.z;
+    if (vb > vmaxb) { vmaxb = vb; bestb = {pb[q].x, pb[q].y, pb[q].z}; }
   }
-  V3 best2 = {cb.x, cb.y, cb.z};
-  double vmax2 = best2.x * db.x + best2.y * db.y + best2.z * db.z, rec2 = cb.w;
-  {
-    const double val = tb.x * db.x + tb.y * db.y + tb.z * db.z;
-    if (val > vmax2) { vmax2 = val; rec2 = tb.w; best2 = {tb.x, tb.y, tb.z}; }
+  int na = only_b ? 0 : __double2loint(pa[0].w) - BS_CAND_K, nb = __double2loint(pb[0].w) - BS_CAND_K;  // candidates left
+  int ka = __double2hiint(pa[0].w), kb = __double2hiint(pb[0].w);
+  NPT(6, 1) NPT(7, __popcll(__ballot(1)))
+  while (na > 0 || nb > 0) {
+    NPT(6, 1) NPT(7, __popcll(__ballot(1)))
+    // (a hull that is done re-reads its last records: the comparisons cannot change its vertex)
+    const int la = na > 0 ? na : 0, lb = nb > 0 ? nb : 0;
+#pragma unroll
+    for (int q = 0; q < BS_CAND_K; q++) {
+      pa[q] = ld_rec32(a.more_all, ka + (q < la ? q : 0));
+      pb[q] = ld_rec32(b.more_all, kb + (q < lb ? q : 0));
+    }
+#pragma unroll
+    for (int q = 0; q < BS_CAND_K; q++) {
+      const double va = pa[q].x * da.x + pa[q].y * da.y + pa[q].z * da.z;
+      if (q < la && va > vmaxa) { vmaxa = va; besta = {pa[q].x, pa[q].y, pa[q].z}; }
+      const double vb = pb[q].x * db.x + pb[q].y * db.y + pb[q].z * db.z;
+      if (q < lb && vb > vmaxb) { vmaxb = vb; bestb = {pb[q].x, pb[q].y, pb[q].z}; }
+    }
+    if (na > 0) { ka += BS_CAND_K; na -= BS_CAND_K; }
+    if (nb > 0) { kb += BS_CAND_K; nb -= BS_CAND_K; }
   }
-  V3 d = da, besta = best;
-  const double4* nbr = a.nbr4;  // one global record array for every hull
-  int second = 0;
-  if (only_b) { second = 1; d = db; vmax = vmax2; rec = rec2; best = best2; }
-  int prev = rec_id(rec), imax = prev;
-  int k = rec_k0(rec), k1 = k + rec_deg(rec);
-  for (;;) {
-    // up to MD_BATCH neighbour records per trip, all loads issued before the first comparison: a
-    // vertex of the usual degree (6) is scanned in ONE memory round trip.  The second half is only
-    // loaded by lanes whose vertex has more than four neighbours left (same order of comparisons as
-    // the four-at-a-time loop: bitwise the same climb).
-    double4 p[MD_BATCH];
-#pragma unroll
-    for (int q = 0; q < 4; q++) p[q] = ld_rec32(nbr, k + q < k1 ? k + q : k1 - 1);
-    const bool more = k + 4 < k1;
-    if (more) {
-#pragma unroll
-      for (int q = 4; q < MD_BATCH; q++) p[q] = ld_rec32(nbr, k + q < k1 ? k + q : k1 - 1);
-    }
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-      const double val = p[q].x * d.x + p[q].y * d.y + p[q].z * d.z;
-      if (val > vmax) { vmax = val; rec = p[q].w; imax = rec_id(rec); best = {p[q].x, p[q].y, p[q].z}; }
-    }
-    if (more) {
-#pragma unroll
-      for (int q = 4; q < MD_BATCH; q++) {
-        const double val = p[q].x * d.x + p[q].y * d.y + p[q].z * d.z;
-        if (val > vmax) { vmax = val; rec = p[q].w; imax = rec_id(rec); best = {p[q].x, p[q].y, p[q].z}; }
-      }
-    }
-    k += MD_BATCH;
-    if (k < k1) continue;          // more neighbours of this vertex
-    if (imax != prev) {            // moved: scan the new vertex
-      prev = imax; k = rec_k0(rec); k1 = k + rec_deg(rec);
-      continue;
-    }
-    if (second) break;             // both hulls done
-    a.cache = imax; besta = best;  // hull 1 done: switch to hull 2
-    second = 1; d = db; vmax = vmax2; rec = rec2; best = best2;
-    prev = imax = rec_id(rec); k = rec_k0(rec); k1 = k + rec_deg(rec);
-  }
-  b.cache = imax;
   Spt s;
   {
     const V3 w = mrot(a.R, besta);
     s.v1 = {a.xpos.x + w.x + a.margin * dir.x, a.xpos.y + w.y + a.margin * dir.y, a.xpos.z + w.z + a.margin * dir.z};
   }
   {
-    const V3 w = mrot(b.R, best);
+    const V3 w = mrot(b.R, bestb);
     s.v2 = {b.xpos.x + w.x + b.margin * nd.x, b.xpos.y + w.y + b.margin * nd.y, b.xpos.z + w.z + b.margin * nd.z};
   }
   s.v = sub(s.v1, s.v2);
@@ -773,6 +772,7 @@ __device__ inline void col_narrowphase(const ColModel& cm, const DevData& d, con
     o.nbr4 = cm.hull_nbr4; o.cache = 0;
     o.start4 = cm.hull_start4 + (size_t)mesh * BS_NSTART;
     o.vert_all = cm.hull_vert4; o.start_all = cm.hull_start4; o.vbase = cm.mesh_vertadr[mesh]; o.sbase = mesh * BS_NSTART;
+    o.cand_all = cm.hull_cand4; o.more_all = cm.hull_more4;
     o.xpos = {AT(c.geom_xpos, 3 * g), AT(c.geom_xpos, 3 * g + 1), AT(c.geom_xpos, 3 * g + 2)};
     for (int k = 0; k < 9; k++) o.R.a[k] = AT(c.geom_xmat, 9 * g + k);
     o.margin = 0;
@@ -877,7 +877,7 @@ __device__ inline void col_narrowphase(const ColModel& cm, const DevData& d, con
 // support call of the hull along -normal (its partner is a dummy hull whose climb ends at once).
 // Same arithmetic per item as col_narrowphase<false>: bitwise the same candidates.
 __device__ inline void col_narrow_persistent(const ColModel& cm, const DevData& d, const ColData& c, unsigned first,
-                                             unsigned last, const unsigned* pre, const int* items, long subcap,
+                                             unsigned last, const unsigned* pre, const int4* items, long subcap,
                                              unsigned* acc, MprState& M) {
   const long E = d.E;
   const int lane = threadIdx.x & 63;
@@ -901,14 +901,25 @@ __device__ inline void col_narrow_persistent(const ColModel& cm, const DevData& 
   a.type = b.type = BS_GEOM_MESH; a.size = b.size = {0, 0, 0};
   a.vert4 = b.vert4 = cm.hull_vert4; a.nbr4 = b.nbr4 = cm.hull_nbr4; a.start4 = b.start4 = cm.hull_start4;
   a.vert_all = b.vert_all = cm.hull_vert4; a.start_all = b.start_all = cm.hull_start4;
+  a.cand_all = b.cand_all = cm.hull_cand4; a.more_all = b.more_all = cm.hull_more4;
   a.vbase = b.vbase = 0; a.sbase = b.sbase = 0;
   a.cache = b.cache = 0; a.margin = b.margin = 0;
   a.xpos = b.xpos = {0, 0, 0};
   for (int k = 0; k < 9; k++) { a.R.a[k] = 0; b.R.a[k] = 0; }
+#ifdef NP_TIMING
+  unsigned long long np_t[24];
+  for (int k = 0; k < 24; k++) np_t[k] = 0;
+  unsigned long long np_last = clock64();
+#define NPT_CLK(i) { const unsigned long long now_ = clock64(); np_t[i] += now_ - np_last; np_last = now_; }
+#else
+#define NPT_CLK(i)
+#endif
   for (;;) {
     // ---- lanes without an item take the next ones of the wavefront's range
     const unsigned long long need = __ballot(!busy);
+    NPT(3, 1)
     if (need) {
+      NPT(4, __popcll(need))
       const unsigned i = cursor + (unsigned)__popcll(need & lower);
       cursor += (unsigned)__popcll(need);
       if (!busy && i < last) {
@@ -916,34 +927,36 @@ __device__ inline void col_narrow_persistent(const ColModel& cm, const DevData& 
         // sub-list never decreases and the search resumes where its last one ended (a step or none, not six)
         while (pre[sublist + 1] <= i) sublist++;  // i < last <= pre[BS_NSUB]
         const int lo = sublist;
-        const int it = items[lo * subcap + (i - pre[lo])];
-        e = d.env0 + (it >> 8); slot = it & 255;
-        const int p = (c.crec ? c.crec[(size_t)e * cm.maxcand + slot].pair : AT(c.cand_pair, slot)) & BS_PAIR_MASK;
+        const int4 it = items[lo * subcap + (i - pre[lo])];
+        e = d.env0 + (it.x >> 8); slot = it.x & 255;
+        const int p = it.y & BS_PAIR_MASK;
         const int4 r0 = *(const int4*)(cm.pair_np + 8 * p), r1 = *(const int4*)(cm.pair_np + 8 * p + 4);
-        const int g1 = r0.x & 0xffff, g2 = r0.y;
+        const int g1 = it.z & 0xffff, g2 = it.z >> 16 & 0xffff;
+        // frames: one 96-byte record per geom (c.gframe) or the [row][E] arrays; both are fetched whole before anything
+        // that depends on the pair record (plane or hull pair) is decided, so they travel with it
+        double F1[12], F2[12];
+        if (c.gframe) {
+          const double* f1 = c.gframe + ((size_t)e * cm.ngeom + g1) * 12;
+          const double* f2 = c.gframe + ((size_t)e * cm.ngeom + g2) * 12;
+#pragma unroll
+          for (int k = 0; k < 12; k++) { F1[k] = f1[k]; F2[k] = f2[k]; }
+        } else {
+#pragma unroll
+          for (int k = 0; k < 3; k++) { F1[k] = AT(c.geom_xpos, 3 * g1 + k); F2[k] = AT(c.geom_xpos, 3 * g2 + k); }
+#pragma unroll
+          for (int k = 0; k < 9; k++) { F1[3 + k] = AT(c.geom_xmat, 9 * g1 + k); F2[3 + k] = AT(c.geom_xmat, 9 * g2 + k); }
+        }
         plane = (r0.x >> 16) != 0;
         margin = __hiloint2double(r1.w, r1.z);
         b.vbase = r1.x; b.sbase = r1.y;
         b.cache = 0;
-        // frames: one 96-byte record per geom (c.gframe) or the [row][E] arrays
-        const double* f1 = c.gframe ? c.gframe + ((size_t)e * cm.ngeom + g1) * 12 : nullptr;
-        const double* f2 = c.gframe ? c.gframe + ((size_t)e * cm.ngeom + g2) * 12 : nullptr;
-        if (f2) {
-          b.xpos = {f2[0], f2[1], f2[2]};
-          for (int k = 0; k < 9; k++) b.R.a[k] = f2[3 + k];
-        } else {
-          b.xpos = {AT(c.geom_xpos, 3 * g2), AT(c.geom_xpos, 3 * g2 + 1), AT(c.geom_xpos, 3 * g2 + 2)};
-          for (int k = 0; k < 9; k++) b.R.a[k] = AT(c.geom_xmat, 9 * g2 + k);
-        }
+        b.xpos = {F2[0], F2[1], F2[2]};
+#pragma unroll
+        for (int k = 0; k < 9; k++) b.R.a[k] = F2[3 + k];
         iters = 0;
         if (plane) {
-          if (f1) {
-            pn = {f1[3 + 2], f1[3 + 5], f1[3 + 8]};
-            pp = {f1[0], f1[1], f1[2]};
-          } else {
-            pn = {AT(c.geom_xmat, 9 * g1 + 2), AT(c.geom_xmat, 9 * g1 + 5), AT(c.geom_xmat, 9 * g1 + 8)};
-            pp = {AT(c.geom_xpos, 3 * g1), AT(c.geom_xpos, 3 * g1 + 1), AT(c.geom_xpos, 3 * g1 + 2)};
-          }
+          pn = {F1[3 + 2], F1[3 + 5], F1[3 + 8]};
+          pp = {F1[0], F1[1], F1[2]};
           b.margin = 0;
           // the partner is not climbed (md_support's only_b): it points at the same hull so its start loads are valid
           a.vbase = b.vbase; a.sbase = b.sbase; a.cache = 0; a.margin = 0;
@@ -951,22 +964,31 @@ __device__ inline void col_narrow_persistent(const ColModel& cm, const DevData& 
         } else {
           a.vbase = r0.z; a.sbase = r0.w;
           a.cache = 0;
-          if (f1) {
-            a.xpos = {f1[0], f1[1], f1[2]};
-            for (int k = 0; k < 9; k++) a.R.a[k] = f1[3 + k];
-          } else {
-            a.xpos = {AT(c.geom_xpos, 3 * g1), AT(c.geom_xpos, 3 * g1 + 1), AT(c.geom_xpos, 3 * g1 + 2)};
-            for (int k = 0; k < 9; k++) a.R.a[k] = AT(c.geom_xmat, 9 * g1 + k);
-          }
+          a.xpos = {F1[0], F1[1], F1[2]};
+#pragma unroll
+          for (int k = 0; k < 9; k++) a.R.a[k] = F1[3 + k];
           a.margin = 0.5 * margin; b.margin = 0.5 * margin;
           mpr_begin(M, a.xpos, b.xpos);
         }
         busy = true;
       }
     }
+    NPT_CLK(0)
     if (!__ballot(busy)) break;
+    NPT(5, __popcll(__ballot(busy)))
+#ifdef NP_TIMING
+    {
+      const int st = plane ? 5 : (M.pk & 7);
+      for (int q = 0; q < 6; q++) { const unsigned long long bq = __ballot(busy && st == q); NPT(8 + q, bq != 0) NPT(14 + q, __popcll(bq)) }
+    }
+#endif
     if (busy) {
+#ifdef NP_TIMING
+      const Spt s = md_support(a, b, M.d, plane, np_t);
+#else
       const Spt s = md_support(a, b, M.d, plane);
+#endif
+      NPT_CLK(1)
       bool fin, hit = false;
       double dist = 0;
       V3 pos = {0, 0, 0}, nrm = {0, 0, 0};
@@ -1004,7 +1026,12 @@ __device__ inline void col_narrow_persistent(const ColModel& cm, const DevData& 
         busy = false;
       }
     }
+    NPT_CLK(2)
   }
+#ifdef NP_TIMING
+  if (lane == 0 && c.stat)
+    for (int k = 0; k < 20; k++) atomicAdd(c.stat + 8 + k, np_t[k]);
+#endif
 }
 
 // A6, work-stealing form: the lanes of a block pull (environment, candidate slot) items from a

@@ -1071,6 +1071,8 @@ __device__ __forceinline__ void tp_collide_prep(const DevModel& m, const TpModel
   // (a wavefront runs the fifteen-axis test when any of its lanes needs it: over all pairs that was every
   // trip, over the survivors it is one trip or two), then the ordered reservation of candidate slots.
   const tp_lds_i L = (tp_lds_i)((tp_lds_d)gfr + TP_ENVS * cm.ngeom * TPG_SLOT) + (tid / TP_LPE) * cm.npair;
+  // per candidate slot: pair | sub-contact << 24 and geom1 | geom2 << 16, for the work-list items below
+  const tp_lds_i PL = (tp_lds_i)((tp_lds_d)gfr + TP_ENVS * cm.ngeom * TPG_SLOT) + TP_ENVS * cm.npair + (tid / TP_LPE) * 2 * cm.maxcand;
   const tp_mask lower = tp_bit(l) - 1;
   int nlist = 0;
   for (int p0 = 0; p0 < cm.npair; p0 += TP_LPE) {
@@ -1122,12 +1124,16 @@ __device__ __forceinline__ void tp_collide_prep(const DevModel& m, const TpModel
     const tp_mask m1 = tp_env_bits(__ballot(cnt & 1), base), m2 = tp_env_bits(__ballot(cnt & 2), base),
                   m8 = tp_env_bits(__ballot(cnt & 8), base);
     const int at = count + tp_popc(m1 & lower) + 2 * tp_popc(m2 & lower) + 8 * tp_popc(m8 & lower);
-    if (env_ok)
+    if (env_ok && cnt) {
+      const int gg = cm.pair_bp[4 * p];
+      const int g12 = (gg & 0xfff) | ((gg >> 12 & 0xfff) << 16);
       for (int q = 0; q < cnt; q++)
         if (at + q < cm.maxcand) {
           if (cd.crec) cd.crec[(size_t)e * cm.maxcand + at + q].pair = p | (q << 24);
           else AT(cd.cand_pair, at + q) = p | (q << 24);
+          PL[2 * (at + q)] = p | (q << 24); PL[2 * (at + q) + 1] = g12;
         }
+    }
     count += tp_popc(m1) + 2 * tp_popc(m2) + 8 * tp_popc(m8);
   }
   if (l == 0 && env_ok) {
@@ -1142,15 +1148,18 @@ __device__ __forceinline__ void tp_collide_prep(const DevModel& m, const TpModel
   if (l == 0 && env_ok && count > 0)
     off = (int)atomicAdd(cd.stat + BS_STAT_ITEMS + d.range * BS_NSUB + sub, (unsigned long long)count);
   off = __builtin_amdgcn_ds_bpermute(base * 4, off);
+  tp_wave_sync();
   if (env_ok) {
     // a sub-list holds every candidate of its environments, so the reservation fits whenever the counters
     // were cleared by the k_tpc pass of the previous step; the test keeps a missed clear (a failed launch)
     // from writing past the list — the narrowphase clamps the lengths the same way
     const long subcap = col_items_subcap(d.n_envs - d.env0, cm.maxcand);
     if (off + count <= subcap) {
-      int* items = cd.items + col_items_base(d.env0, d.range, cm.maxcand) + (long)sub * subcap + off;
+      // an item names everything the narrowphase's set-up loads depend on — environment | slot, pair, both geoms — so
+      // its pair record and its two geom frames are fetched together (one round trip after the item's, not three)
+      int4* items = cd.items + col_items_base(d.env0, d.range, cm.maxcand) + (long)sub * subcap + off;
       const int tag = (int)(env - d.env0) << 8;
-      for (int k = l; k < count; k += TP_LPE) items[k] = tag | k;
+      for (int k = l; k < count; k += TP_LPE) items[k] = make_int4(tag | k, PL[2 * k], PL[2 * k + 1], 0);
     } else if (l == 0) {
       AT(d.warning, 0) |= 8;
     }
