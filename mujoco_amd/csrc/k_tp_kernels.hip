@@ -2,6 +2,11 @@
 // object file: the Makefile compiles this source once per kernel with -DTPK_<name>, so the
 // instantiations (each a few thousand lines of straight-line fp64 code) build in parallel.
 // Block = one 64-lane wavefront = two environments; __launch_bounds__(64, 2) = two waves per SIMD.
+// the contact kernel of CHAIN models forms the sweeps' receive factors where they are used (physics_tp.h::tp_recv_factor):
+// it is short of registers, the contact-free one is not and keeps them hoisted (167 vs 171 M env-steps/s at 4096 envs)
+#ifdef TPK_tpc_chain
+#define TP_RECV_OPAQUE 1
+#endif
 #include "kernels.h"
 // kernel and launcher names: k_<name> / bs_launch_<name>, with the suffix _w in the wide build (-DTP_LPE=64)
 #if TP_LPE == 64

@@ -349,6 +349,17 @@ struct TpCtx {
                          // kernels' branching level: no table read in front of its fetches
   tp_lds_ptr tbl;        // LDS table
 };
+// 1.0 on the lane that receives at level D of a CHAIN sweep (its dof count is D - 1 and its child dof sits on the next
+// lane), 0.0 elsewhere.  TP_RECV_OPAQUE (the contact kernel): formed from an opaque copy of the dof count where it is
+// used — hoisted out of the solver loop the factors of the four shifted levels were eight more registers live through
+// the whole kernel (scratch 184 -> 152 B per lane)
+__device__ __forceinline__ double tp_recv_factor(const TpCtx& c, int D) {
+  int dd = c.dd;
+#ifdef TP_RECV_OPAQUE
+  asm volatile("" : "+v"(dd));
+#endif
+  return dd == D - 1 && c.dchild0 == c.self_sa + 4 ? 1.0 : 0.0;
+}
 // ds_bpermute address of child ch >= 1 of this lane (row0 = TPL_BCHILD or TPL_DCHILD)
 __device__ __forceinline__ int tp_child(tp_lds_ptr tbl, int row0, int ch) {
   const int w = tbl[(row0 + ((ch - 1) >> 2)) * 64 + threadIdx.x];
@@ -407,7 +418,7 @@ __device__ TP_HELPER_ATTR TpFac tp_factor(TpCtx c, TpRow Rin) {
     if (is) dinv = ir0;
     if (D == 1) break;
     const bool par = c.dd == D - 1;
-    const double rm = par && c.dchild0 == c.self_sa + 4 ? 1.0 : 0.0;  // CHAIN: the child dof is on the next lane
+    const double rm = tp_recv_factor(c, D);  // CHAIN: 1 on the lane whose child dof is on the next lane
     auto round = [&](int ch) {
       const int src = ch == 0 ? c.dchild0 : (CHAIN && D == 2 ? tp_child_w(c.dchild_w, ch) : tp_child(c.tbl, TPL_DCHILD, ch));
       const int sa = par ? src : c.zero_sa;
@@ -495,7 +506,7 @@ __device__ TP_HELPER_ATTR double tp_factor_solve(TpCtx c, TpRow Rin, double x) {
     if (is) dinv = ir0;
     if (D == 1) break;
     const bool par = c.dd == D - 1;
-    const double rm = par && c.dchild0 == c.self_sa + 4 ? 1.0 : 0.0;  // CHAIN: the child dof is on the next lane
+    const double rm = tp_recv_factor(c, D);  // CHAIN: 1 on the lane whose child dof is on the next lane
     auto round = [&](int ch) {
       const int src = ch == 0 ? c.dchild0 : (CHAIN && D == 2 ? tp_child_w(c.dchild_w, ch) : tp_child(c.tbl, TPL_DCHILD, ch));
       const int sa = par ? src : c.zero_sa;
@@ -562,7 +573,7 @@ __device__ TP_HELPER_ATTR void tp_factor2(TpCtx c, TpRow R0in, TpRow R1in, TpFac
     }
     if (D == 1) break;
     const bool par = c.dd == D - 1;
-    const double rm = par && c.dchild0 == c.self_sa + 4 ? 1.0 : 0.0;  // CHAIN: the child dof is on the next lane
+    const double rm = tp_recv_factor(c, D);  // CHAIN: 1 on the lane whose child dof is on the next lane
     auto round = [&](int ch) {
       const int src = ch == 0 ? c.dchild0 : (CHAIN && D == 2 ? tp_child_w(c.dchild_w, ch) : tp_child(c.tbl, TPL_DCHILD, ch));
       const int sa = par ? src : c.zero_sa;
@@ -606,7 +617,7 @@ __device__ TP_HELPER_ATTR double tp_solve(TpCtx c, TpRow Rin, double dinv, doubl
   for (int D = TP_MAXD; D >= 2; D--) {
     if (D > c.maxdd) continue;
     const bool par = c.dd == D - 1;
-    const double rm = par && c.dchild0 == c.self_sa + 4 ? 1.0 : 0.0;  // CHAIN: the child dof is on the next lane
+    const double rm = tp_recv_factor(c, D);  // CHAIN: 1 on the lane whose child dof is on the next lane
     double T[TP_MAXD];
 #pragma unroll
     for (int a = 1; a < TP_MAXD; a++)
@@ -662,7 +673,7 @@ __device__ TP_HELPER_ATTR double tp_solve_mulm(TpCtx c, TpRow Rin, double dinv, 
   for (int D = TP_MAXD; D >= 2; D--) {
     if (D > c.maxdd) continue;
     const bool par = c.dd == D - 1;
-    const double rm = par && c.dchild0 == c.self_sa + 4 ? 1.0 : 0.0;  // CHAIN: the child dof is on the next lane
+    const double rm = tp_recv_factor(c, D);  // CHAIN: 1 on the lane whose child dof is on the next lane
     double T[TP_MAXD], U[TP_MAXD];
 #pragma unroll
     for (int a = 1; a < TP_MAXD; a++)
@@ -704,7 +715,7 @@ __device__ TP_HELPER_ATTR void tp_solve_n(TpCtx c, TpRow Rin, double dinv, doubl
   for (int D = TP_MAXD; D >= 2; D--) {
     if (D > c.maxdd) continue;
     const bool par = c.dd == D - 1;
-    const double rm = par && c.dchild0 == c.self_sa + 4 ? 1.0 : 0.0;  // CHAIN: the child dof is on the next lane
+    const double rm = tp_recv_factor(c, D);  // CHAIN: 1 on the lane whose child dof is on the next lane
     double T[N][TP_MAXD];
 #pragma unroll
     for (int n = 0; n < N; n++)
@@ -779,7 +790,7 @@ __device__ TP_HELPER_ATTR double tp_mul_m(TpCtx c, TpRow Min, double v) {
   for (int D = TP_MAXD; D >= 2; D--) {
     if (D > c.maxdd) continue;
     const bool par = c.dd == D - 1;
-    const double rm = par && c.dchild0 == c.self_sa + 4 ? 1.0 : 0.0;  // CHAIN: the child dof is on the next lane
+    const double rm = tp_recv_factor(c, D);  // CHAIN: 1 on the lane whose child dof is on the next lane
     double T[TP_MAXD];
 #pragma unroll
     for (int a = 1; a < TP_MAXD; a++)
