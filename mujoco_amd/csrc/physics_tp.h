@@ -1017,12 +1017,16 @@ __device__ __forceinline__ void tp_collide_prep(const DevModel& m, const TpModel
   const int jnt = t.lane[TPI_JNT * TP_LPE + l];
   const bool has_dof = jnt >= 0, isb = l < m.nbody && l > 0;
   const int b = l < m.nbody ? l : 0, j = has_dof ? jnt : 0;
-  const V3 bpos = ld3(m.body_pos + 3 * b), jpos = ld3(m.jnt_pos + 3 * j), jax = ld3(m.jnt_axis + 3 * j);
-  const Q4 bquat = ld4(m.body_quat + 4 * b);
+  // (the state is loaded on every lane, row 0 where there is no dof, and selected afterwards: guarded loads were
+  // emitted one behind the other, each with its own wait; the pose constants come from the lane's one record)
+  const double qpos_l = AT(d.qpos, j), qvel_l = AT(d.qvel, j);
+  const double* const lk = t.lane_k + l * TPK_N;
+  const V3 bpos = ld3(lk + TPK_BPOS), jpos = ld3(lk + TPK_JPOS), jax = ld3(lk + TPK_JAX);
+  const Q4 bquat = ld4(lk + TPK_BQUAT);
   const int jtype = m.jnt_type[j];
   const double qpos0 = m.qpos0[j];
-  double qpos = has_dof ? AT(d.qpos, j) : 0.0;
-  const double qvel = has_dof ? AT(d.qvel, j) : 0.0;
+  double qpos = has_dof ? qpos_l : 0.0;
+  const double qvel = has_dof ? qvel_l : 0.0;
   if (env_any(has_dof && (bad_num(qpos) || bad_num(qvel)), base)) qpos = qpos0;
   const double dq = qpos - qpos0;
   Q4 lq = bquat;
@@ -1220,9 +1224,56 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
   unsigned long long tacc[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = clock64();
 #endif
   const int l = tid & (TP_LPE - 1), base = tid & ~(TP_LPE - 1);
+  // Prologue (round 3): every load of the lane table, of the lane's model constants and of the state is issued
+  // before the first wait.  Written the obvious way (`has_dof ? AT(d.qpos, j) : 0.0` per field, the LDS table built
+  // first) the compiler emitted one guarded load per field, each behind its own s_waitcnt vmcnt(0) and a reload of
+  // the kernel arguments: a dozen dependent memory round trips per wavefront with two wavefronts per SIMD to hide
+  // them.  Indices are clamped instead (j = 0, act = 0 on lanes without one) and the values selected afterwards.
   // lane table: lane references become ds_bpermute byte addresses; child lists and ancestor
   // masks go to LDS, everything else straight into registers
   auto lane_ref = [&](int f) { const int v = t.lane[f * TP_LPE + l]; return v >= 0 ? (base + v) * 4 : v; };
+  long env = d.env0 + (long)tp_block() * TP_ENVS + (tid / TP_LPE);
+  const bool env_ok = env < d.n_envs;
+  if (!env_ok) env = d.n_envs - 1;
+  const long E = d.E, e = env;
+  const int self_sa = tid * 4;
+  const int par_sa = lane_ref(TPI_PARENT);
+  const int depth = t.lane[TPI_DEPTH * TP_LPE + l], jnt = t.lane[TPI_JNT * TP_LPE + l];
+  const int root = t.lane[TPI_ROOT * TP_LPE + l], act = t.lane[TPI_ACT * TP_LPE + l];
+  const int eq_own = t.lane[TPI_EQ_OWN * TP_LPE + l], eq_pos = t.lane[TPI_EQ_POS * TP_LPE + l];
+  const int eq_other_raw = lane_ref(TPI_EQ_OTHER), eq_src_raw = lane_ref(TPI_EQ_SRC);
+  const int dd_raw = t.lane[TPI_DD * TP_LPE + l];
+  const int eq_other_sa = eq_other_raw >= 0 ? eq_other_raw : self_sa;
+  const int eq_src_sa = eq_src_raw >= 0 ? eq_src_raw : self_sa;
+  const bool has_dof = jnt >= 0, is_src = eq_src_raw >= 0;
+  const bool isb = l < m.nbody && l > 0;
+  const int b = l < m.nbody ? l : 0, j = has_dof ? jnt : 0, ja = act >= 0 ? act : 0;
+  // state and the lane's model constants (clamped indices: every lane loads)
+  const double qpos_l = AT(d.qpos, j), qvel_l = AT(d.qvel, j), qfa_l = AT(d.qfrc_applied, j), qacc_l = AT(d.qacc, j);
+  const double qws_l = AT(d.qacc_warmstart, j), ctrl_l = AT(d.ctrl, ja);
+  const int jtype = m.jnt_type[j];
+  const double mass_l = m.body_mass[b], qpos0 = m.qpos0[j], damping_l = m.dof_damping[j];
+  double time = AT(d.time, 0);
+  int warning = AT(d.warning, 0), solver_iter = AT(d.solver_iter, 0), nefc = AT(d.nefc, 0);
+  int ncand_pre = 0;  // candidate count of the environment: requested here, needed at the contact assembly
+  if constexpr (CON) ncand_pre = AT(cd.ncand, 0);
+  TpCtx c;
+  c.self_sa = self_sa; c.zero_sa = (base + TP_LPE - 1) * 4; c.dd = has_dof ? dd_raw : 0; c.maxdd = t.maxdd; c.tbl = (tp_lds_ptr)tbl;
+  c.dchild0 = lane_ref(TPI_DCHILD);
+  if (c.dchild0 < 0) c.dchild0 = (base + TP_LPE - 1) * 4;
+  int bchild0 = lane_ref(TPI_BCHILD);
+  if (bchild0 < 0) bchild0 = (base + TP_LPE - 1) * 4;
+#pragma unroll
+  for (int a = 0; a < TP_MAXD; a++) {
+    const int v = lane_ref(TPI_ANC + a);
+    c.anc_sa[a] = v >= 0 ? v : self_sa;
+  }
+  c.top_sa = self_sa;
+#pragma unroll
+  for (int a = 1; a < TP_MAXD; a++)
+    if (a == c.dd - 1) c.top_sa = c.anc_sa[a];
+#pragma unroll
+  for (int D = 0; D < TP_MAXD + 2; D++) c.nchild[D] = t.lvl_dchild[D];
   {
     const int zl = base + TP_LPE - 1;  // the environment's zero lane stands for "no child"
     for (int r = 0; r < 2 * TPL_CROWS; r++) {
@@ -1241,54 +1292,19 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
   tbl[TPL_ANCMASK_HI * 64 + tid] = t.lane[TPI_ANCMASK_HI * TP_LPE + l];
 #endif
   __syncthreads();
-  long env = d.env0 + (long)tp_block() * TP_ENVS + (tid / TP_LPE);
-  const bool env_ok = env < d.n_envs;
-  if (!env_ok) env = d.n_envs - 1;
-  const long E = d.E, e = env;
-  const int self_sa = tid * 4;
-  const int par_sa = lane_ref(TPI_PARENT);
-  const int depth = t.lane[TPI_DEPTH * TP_LPE + l], jnt = t.lane[TPI_JNT * TP_LPE + l];
-  const int root = t.lane[TPI_ROOT * TP_LPE + l], act = t.lane[TPI_ACT * TP_LPE + l];
-  const int eq_own = t.lane[TPI_EQ_OWN * TP_LPE + l], eq_pos = t.lane[TPI_EQ_POS * TP_LPE + l];
-  const int eq_other_raw = lane_ref(TPI_EQ_OTHER), eq_src_raw = lane_ref(TPI_EQ_SRC);
-  const int eq_other_sa = eq_other_raw >= 0 ? eq_other_raw : self_sa;
-  const int eq_src_sa = eq_src_raw >= 0 ? eq_src_raw : self_sa;
-  const bool has_dof = jnt >= 0, is_src = eq_src_raw >= 0;
-  const bool isb = l < m.nbody && l > 0;
-  const int b = l < m.nbody ? l : 0, j = has_dof ? jnt : 0;
-  TpCtx c;
-  c.self_sa = self_sa; c.zero_sa = (base + TP_LPE - 1) * 4; c.dd = has_dof ? t.lane[TPI_DD * TP_LPE + l] : 0; c.maxdd = t.maxdd; c.tbl = (tp_lds_ptr)tbl;
-  c.dchild0 = lane_ref(TPI_DCHILD);
-  if (c.dchild0 < 0) c.dchild0 = (base + TP_LPE - 1) * 4;
-  c.dchild_w = tbl[TPL_DCHILD * 64 + tid];  // (after the barrier below; the CHAIN kernels keep it for the whole launch)
-  int bchild0 = lane_ref(TPI_BCHILD);
-  if (bchild0 < 0) bchild0 = (base + TP_LPE - 1) * 4;
-#pragma unroll
-  for (int a = 0; a < TP_MAXD; a++) {
-    const int v = lane_ref(TPI_ANC + a);
-    c.anc_sa[a] = v >= 0 ? v : self_sa;
-  }
-  c.top_sa = self_sa;
-#pragma unroll
-  for (int a = 1; a < TP_MAXD; a++)
-    if (a == c.dd - 1) c.top_sa = c.anc_sa[a];
-#pragma unroll
-  for (int D = 0; D < TP_MAXD + 2; D++) c.nchild[D] = t.lvl_dchild[D];
+  c.dchild_w = tbl[TPL_DCHILD * 64 + tid];  // (the CHAIN kernels keep it for the whole launch)
 
   // per-lane model constants
   const double* const lk = t.lane_k + l * TPK_N;  // the lane's record of per-step constants
-  const int jtype = m.jnt_type[j];
-  const double mass = isb ? m.body_mass[b] : 0.0, qpos0 = m.qpos0[j];
-  const double damping = has_dof ? m.dof_damping[j] : 0.0;
+  const double mass = isb ? mass_l : 0.0;
+  const double damping = has_dof ? damping_l : 0.0;
   const double h = m.timestep;
   const double scale = tp_rcp(m.meaninertia * (m.nv > 1 ? m.nv : 1));
 
   // state
-  double qpos = has_dof ? AT(d.qpos, j) : 0.0, qvel = has_dof ? AT(d.qvel, j) : 0.0;
-  double qfrc_applied = has_dof ? AT(d.qfrc_applied, j) : 0.0, qacc = has_dof ? AT(d.qacc, j) : 0.0;
-  double qacc_ws = has_dof ? AT(d.qacc_warmstart, j) : 0.0, ctrl = act >= 0 ? AT(d.ctrl, act) : 0.0;
-  double time = AT(d.time, 0);
-  int warning = AT(d.warning, 0), solver_iter = AT(d.solver_iter, 0), nefc = AT(d.nefc, 0);
+  double qpos = has_dof ? qpos_l : 0.0, qvel = has_dof ? qvel_l : 0.0;
+  double qfrc_applied = has_dof ? qfa_l : 0.0, qacc = has_dof ? qacc_l : 0.0;
+  double qacc_ws = has_dof ? qws_l : 0.0, ctrl = act >= 0 ? ctrl_l : 0.0;
   bool was_reset = false;
   auto reset_state = [&]() {
     qpos = has_dof ? qpos0 : 0.0; qvel = 0; ctrl = 0; qfrc_applied = 0; qacc = 0; qacc_ws = 0; time = 0;
@@ -1643,21 +1659,30 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
         myslot = slot0 + l * SL;
         Hs = (tp_lds_d)sh.H + half * (m.nbody * (m.nbody + 1) / 2);
         Us = (tp_lds_d)sh.U + half * (TP_LPE * 3);
-        const int ncand = AT(cd.ncand, 0);
+        const int ncand = ncand_pre;
         int count = 0;
         for (int s0 = 0; s0 < cm.maxcand; s0 += TP_LPE) {
           if (!__ballot(s0 < ncand)) break;
           const int sidx = s0 + l;
           const CandRec* cr = cd.crec ? cd.crec + (size_t)e * cm.maxcand + (sidx < ncand ? sidx : 0) : nullptr;
-          const bool hit = sidx < ncand && (cr ? cr->hit : AT(cd.cand_hit, sidx)) != 0;
+          // the whole 64-byte record in one round of loads (what a slot without a hit holds besides its flag is stale
+          // and unused): flag first, then the fields of the hits, was two dependent round trips
+          int rec_pair = 0, rec_hit = 0;
+          double rec_d[7] = {0, 0, 0, 0, 0, 0, 0};
+          if (cr) {
+            rec_pair = cr->pair; rec_hit = cr->hit; rec_d[0] = cr->dist;
+#pragma unroll
+            for (int k = 0; k < 3; k++) { rec_d[1 + k] = cr->pos[k]; rec_d[4 + k] = cr->nrm[k]; }
+          }
+          const bool hit = sidx < ncand && (cr ? rec_hit : AT(cd.cand_hit, sidx)) != 0;
           const tp_mask bits = tp_env_bits(__ballot(hit), base);
           const int n = count + tp_popc(bits & (tp_bit(l) - 1));
           if (hit && n < cm.maxcon) {
-            const int pr = (cr ? cr->pair : AT(cd.cand_pair, sidx)) & BS_PAIR_MASK;
-            const double dist = cr ? cr->dist : AT(cd.cand_dist, sidx);
-            const V3 p = cr ? V3{cr->pos[0], cr->pos[1], cr->pos[2]}
+            const int pr = (cr ? rec_pair : AT(cd.cand_pair, sidx)) & BS_PAIR_MASK;
+            const double dist = cr ? rec_d[0] : AT(cd.cand_dist, sidx);
+            const V3 p = cr ? V3{rec_d[1], rec_d[2], rec_d[3]}
                             : V3{AT(cd.cand_pos, 3 * sidx), AT(cd.cand_pos, 3 * sidx + 1), AT(cd.cand_pos, 3 * sidx + 2)};
-            const V3 x = normalized(cr ? V3{cr->nrm[0], cr->nrm[1], cr->nrm[2]}
+            const V3 x = normalized(cr ? V3{rec_d[4], rec_d[5], rec_d[6]}
                                        : V3{AT(cd.cand_nrm, 3 * sidx), AT(cd.cand_nrm, 3 * sidx + 1), AT(cd.cand_nrm, 3 * sidx + 2)});
             V3 y = {0, 0, 0};
             if (x.y < 0.5 && x.y > -0.5) y.y = 1;
@@ -2519,8 +2544,12 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
   }
   if (!env_ok) return;
   if (has_dof) {
-    AT(d.qpos, j) = qpos; AT(d.qvel, j) = qvel; AT(d.qacc, j) = qacc; AT(d.qacc_warmstart, j) = qacc_ws;
-    if (was_reset) AT(d.qfrc_applied, j) = qfrc_applied;
+    // (an opaque copy of the row: the prologue's load addresses are formed again here instead of staying live — or in
+    // scratch — through the whole kernel)
+    int jo = j;
+    asm volatile("" : "+v"(jo));
+    AT(d.qpos, jo) = qpos; AT(d.qvel, jo) = qvel; AT(d.qacc, jo) = qacc; AT(d.qacc_warmstart, jo) = qacc_ws;
+    if (was_reset) AT(d.qfrc_applied, jo) = qfrc_applied;
   }
   if (was_reset && act >= 0) AT(d.ctrl, act) = ctrl;
   if (l == 0) {
