@@ -34,6 +34,12 @@
 // fingers) to this many: models with more children there run the generic kernels.  Unrolled to TP_MAXC = 8 a
 // five-fingered hand spent three of eight rounds of every sweep fetching zeros from the zero lane.
 #define TP_CHAIN_MAXC 5
+// rows of the Newton Hessian that the CHAIN contact kernel factorises in registers (0: always the LDS version; models
+// with more bodies take the LDS version at run time).  24 = the exported hands; measured at 65 536 envs: LDS version
+// 40.7 M, 32 rows 41.9 M, 24 rows 42.9 M env-steps/s (the column lives in 2 x TPC_NREG registers during the factorisation)
+#ifndef TPC_NREG
+#define TPC_NREG 24
+#endif
 
 #ifndef TP_HELPER_ATTR
 #define TP_HELPER_ATTR __forceinline__
@@ -1948,6 +1954,79 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
 #endif
           const tp_lds_d Gs = Us;  // the U staging rows are free again
           double greg = g, y = 0;
+#if TP_LPE == 32 && TPC_NREG > 0
+          // Round 3: the factorisation in REGISTERS (CHAIN kernels, n <= TPC_NREG).  Lane k takes COLUMN k of the packed
+          // triangle, h[i] = H(i,k) for i >= k (what it reads for i < k is another row's entry: carried along, never used).
+          // Panel (j1, j0): the 2x2 block and the two right-hand sides come from lanes j1 / j0 by ds_bpermute, every
+          // lane k < j0 scales ITS OWN two entries (a = L(j1,k), b = L(j0,k): registers h[j1], h[j0], static indices),
+          // publishes the pair in LDS, and the trailing update of its column is one broadcast 16-byte read and two FMAs
+          // per row, straight-line: h[i] = (h[i] - a_i a) - b_i b — the same operations in the same order as the packed
+          // round-robin update below, which spent ~65 instructions per trip on row indices, five LDS addresses per
+          // entry and predicates for four FMAs.  Panels are paired statically from row TPC_NREG - 1 down (a two-column
+          // panel is bitwise two single-column eliminations, so the pairing does not change the result); a phantom row
+          // n (n odd) is an identity row: zeros in every column, one on its own lane, a zero right-hand side.  L goes back to the packed triangle for the back substitution.
+          const bool regchol = CHAIN && n <= TPC_NREG;
+          if (regchol) {
+            typedef double tp_d2 __attribute__((ext_vector_type(2)));
+            typedef tp_d2 __attribute__((address_space(3)))* tp_lds_d2;
+            // opaque copies of the lane number and of the half's first permute address: as loop invariants the
+            // compiler hoists every panel's lane masks and permute addresses out of the Newton loop and spills them
+            int lo = l, base4 = base * 4;
+            asm volatile("" : "+v"(lo), "+v"(base4));
+            double h[TPC_NREG];
+            const tp_lds_d Hcol = Hs + l;
+#pragma unroll
+            for (int i = 0; i < TPC_NREG; i++) h[i] = i < n ? Hcol[i * (i + 1) / 2] : (lo == i ? 1.0 : 0.0);  // rows >= n: identity
+            const tp_lds_d2 AB = (tp_lds_d2)Us;  // (a, b) of every lane: one 16-byte entry each (Us is 16-byte aligned)
+            static_assert(TPC_NREG % 2 == 0, "rows are paired (j1 odd, j1 - 1) down to (1, 0)");
+#pragma unroll
+            for (int j1 = TPC_NREG - 1; j1 >= 1; j1 -= 2) {
+              const int j0 = j1 - 1;
+              if (j0 >= n) continue;  // wave-uniform
+              const int sa1 = base4 + 4 * j1, sa0 = base4 + 4 * j0;
+              double d1 = bperm(h[j1], sa1);
+              const double x10 = bperm(h[j1], sa0), d0r = bperm(h[j0], sa0);
+              const double g1 = bperm(greg, sa1), g0 = bperm(greg, sa0);
+              if (d1 < BS_MINVAL) d1 = BS_MINVAL;
+              const double inv1 = tp_rsqrt(d1);
+              const double y1 = g1 * inv1;
+              const double l10 = x10 * inv1;
+              double d0 = d0r - l10 * l10;
+              if (d0 < BS_MINVAL) d0 = BS_MINVAL;
+              const double inv0 = tp_rsqrt(d0);
+              const double y0 = (g0 - l10 * y1) * inv0;
+              const double a = h[j1] * inv1, b = (h[j0] - l10 * a) * inv0;
+              greg -= a * y1;
+              greg -= b * y0;
+              h[j1] = lo < j0 ? a : (lo == j0 ? l10 : inv1);
+              h[j0] = lo < j0 ? b : inv0;
+              if (lo == j0) y = y0;
+              if (lo == j1) y = y1;
+              AB[lo] = tp_d2{a, b};
+              tp_wave_sync();
+              // four rows per round of broadcast reads
+#pragma unroll
+              for (int i0 = 0; i0 < j0; i0 += 4) {
+                tp_d2 ab[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                  if (i0 + q < j0) ab[q] = AB[i0 + q];
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                  if (i0 + q < j0) h[i0 + q] = (h[i0 + q] - ab[q].x * a) - ab[q].y * b;
+              }
+              tp_wave_sync();
+            }
+            if (lo < n) {
+#pragma unroll
+              for (int i = 0; i < TPC_NREG; i++)
+                if (i < n) Hcol[i * (i + 1) / 2] = h[i];  // ascending rows: what a lane k > i writes here lands in a later row and is overwritten
+            }
+            tp_wave_sync();
+          } else {
+#else
+          {
+#endif
           Gs[l] = greg;
           tp_wave_sync();
           for (int j1 = n - 1; j1 >= 0; j1 -= 2) {
@@ -2007,6 +2086,7 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
                 if (q[u] < tj) Hs[q[u]] = (h[u] - ai[u] * ak[u]) - bi[u] * bk[u];
             }
             tp_wave_sync();
+          }
           }
           TPC_TL(7)
           // L x = y (ascending), four unknowns per cross-lane round trip: every lane fetches the four
