@@ -2089,28 +2089,22 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
           }
           }
           TPC_TL(7)
-          // L x = y (ascending), four unknowns per cross-lane round trip: every lane fetches the four
-          // right-hand sides and resolves the 4x4 triangle itself from broadcast reads of L
-          double acc = 0;
-          for (int k0 = 0; k0 < n; k0 += 4) {
-            const double v = y - acc;
-            double xs[4] = {0, 0, 0, 0};
-#pragma unroll
-            for (int jx = 0; jx < 4; jx++) {
-              const int k = k0 + jx;
-              if (k < n) {  // wave-uniform
-                double a = bperm(v, (base + k) * 4);
-                const tp_lds_d Hk = Hs + k * (k + 1) / 2;
-#pragma unroll
-                for (int p2 = 0; p2 < jx; p2++) a -= Hk[k0 + p2] * xs[p2];
-                xs[jx] = a * Hk[k];
-                if (l == k) xres = xs[jx];
-              }
-            }
-            if (l >= k0 + 4 && l < n) {
-#pragma unroll
-              for (int jx = 0; jx < 4; jx++)
-                if (k0 + jx < n) acc += Hrow[k0 + jx] * xs[jx];
+          // L x = y (ascending), one unknown per step: every lane forms its candidate (y - acc) / L(l,l) from what it
+          // has accumulated so far, lane k's is final at step k and goes to all lanes by ds_bpermute, the lanes below
+          // add L(l,k) x_k (one read of the lane's own packed row).  Nine instructions per unknown; the version of
+          // round 2 resolved four unknowns per cross-lane round trip redundantly on every lane from broadcast reads of
+          // L (676 instructions for the hand's 24 rows against ~230, and a longer dependent chain in practice).
+          // What a lane adds after its own step is never used (rows end at the diagonal: it reads past its row).
+          {
+            double acc = 0;
+            const tp_lds_d Lrow = l < n ? Hrow : Hs;  // lanes beyond the bodies read row 0 (their result is unused)
+            const double invl = l < n ? Hrow[l] : 0.0;
+#pragma unroll 4
+            for (int k = 0; k < n; k++) {
+              const double xl = (y - acc) * invl;
+              const double xk = bperm(xl, (base + k) * 4);
+              if (l == k) xres = xl;
+              acc += Lrow[k] * xk;
             }
           }
           TPC_TL(8)
