@@ -204,6 +204,25 @@ static void build_tp(bs_model* mdl, int variant) {
     at(TPI_ANCMASK, b) = (int32_t)(uint32_t)mask;
     at(TPI_ANCMASK_HI, b) = (int32_t)(uint32_t)(mask >> 32);
   }
+  // derived rows (TPI_SA_*, TPI_CW): environment-relative permute byte offsets with the fallbacks resolved, child words
+  for (int l = 0; l < LPE; l++) {
+    auto rel4 = [&](int v, int fallback) { return 4 * (v >= 0 ? v : fallback); };
+    for (int a = 0; a < TP_MAXD; a++) at(TPI_SA_ANC + a, l) = rel4(at(TPI_ANC + a, l), l);
+    at(TPI_SA_EQO, l) = rel4(at(TPI_EQ_OTHER, l), l);
+    at(TPI_SA_EQS, l) = rel4(at(TPI_EQ_SRC, l), l);
+    at(TPI_SA_DC0, l) = rel4(at(TPI_DCHILD, l), LPE - 1);
+    at(TPI_SA_BC0, l) = rel4(at(TPI_BCHILD, l), LPE - 1);
+    for (int r = 0; r < 2 * TPL_CROWS; r++) {
+      const int first = (r < TPL_CROWS ? TPI_BCHILD : TPI_DCHILD) + 1 + 4 * (r % TPL_CROWS);
+      int w = 0;
+      for (int k = 0; k < 4; k++) {
+        const int ch = 1 + 4 * (r % TPL_CROWS) + k;
+        const int v = ch < TP_MAXC ? at(first + k, l) : -1;
+        w |= (v >= 0 ? v : LPE - 1) << (8 * k);
+      }
+      at(TPI_CW + r, l) = w;
+    }
+  }
   // state-independent parts of the constraint rows, with the kernels' own functions
   std::vector<double>& Dt = m->tp_dtable;
   Dt.assign((size_t)TPD_TOTAL * LPE, 0.0);
@@ -797,7 +816,7 @@ static int model_image(bs_model* m, int device, const DeviceImage** out) {
     int kind = 0, has_box = 0;
     double thresh = 0.0;
     if (r1 > 0 && r2 > 0) {
-      kind = 1; thresh = margin + r1 + r2;
+      kind = 1; thresh = (margin + r1 + r2) * (margin + r1 + r2);  // the SQUARED distance is compared (no square root per pair)
       has_box = obb[6 * g1 + 3] >= 0 && obb[6 * g2 + 3] >= 0;
     } else if (s.geom_type[g1] == BS_GEOM_PLANE && r2 > 0) {
       kind = 2; thresh = margin + r2;

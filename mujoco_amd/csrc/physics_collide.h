@@ -62,7 +62,7 @@ struct ColModel {
   // what the persistent narrowphase needs about a pair in one 32-byte record (instead of pair -> geoms ->
   // mesh tables, three dependent levels of loads per item): geom1 | plane << 16, geom2, first vertex record and
   // start-table row of hull 1 and of hull 2; the pair's margin = max of the geoms' follows as a double
-  const int *pair_bp;      // [npair][4]: g1 | g2 << 12 | kind << 24 (1 spheres, 2 plane) | obb << 26, 0, threshold of the bounding test (one double)
+  const int *pair_bp;      // [npair][4]: g1 | g2 << 12 | kind << 24 (1 spheres, 2 plane) | obb << 26, 0, threshold of the bounding test (one double; spheres: squared)
   const int *pair_np;      // [npair][8]: g1 | plane << 16, g2, vbase1, sbase1, vbase2, sbase2, margin (2 ints = one double)
   int nl_min_share;        // least number of work-list items a wavefront of k_c_narrow_list takes
   int has_prim;            // some pair involves a primitive geom: the narrowphase kernels' PRIM instantiation runs

@@ -55,7 +55,15 @@ enum {
   TPI_FRIC_ROW = TPI_COUNT, TPI_LIM_ROW,
   TPI_ANCMASK,  // bit k set: body lane k carries a dof on the path from this body to the root (itself included)
   TPI_ANCMASK_HI,  // lanes 32..63 (wide build)
-  TPI_TOTAL
+  // derived rows (host, build_tp): what the kernels' prologue would otherwise form from the rows above with a handful
+  // of instructions per entry — environment-relative ds_bpermute BYTE offsets with the fallbacks resolved (the kernel
+  // adds its half's first lane), and the LDS child table's words (children 1.. as lane bytes, four per word)
+  TPI_SA_ANC,                                // + a: the a-th ancestor dof's lane (own lane if none)
+  TPI_SA_EQO = TPI_SA_ANC + TP_MAXD,         // lane of the equality's other dof (own lane if none)
+  TPI_SA_EQS,                                // lane of the equality that reads this dof (own lane if none)
+  TPI_SA_DC0, TPI_SA_BC0,                    // first dof / body child (the zero lane if none)
+  TPI_CW,                                    // + r, r < 2 * TPL_CROWS: body-child words, then dof-child words
+  TPI_TOTAL = TPI_CW + 2 * ((TP_MAXC - 1 + 3) / 4)
 };
 
 // fields kept in LDS (indexed inside loops or by another lane's id); the rest is read once
@@ -1108,7 +1116,7 @@ __device__ __forceinline__ void tp_collide_prep(const DevModel& m, const TpModel
       keep = true;
       if (kind == 1) {
         const V3 df = sub(x1, x2);
-        keep = !(sqrt(dot(df, df)) > thresh);
+        keep = !(dot(df, df) > thresh);  // thresh = (margin + r1 + r2)^2: a conservative filter needs no square root (~30 instructions per pair trip)
         obb = keep && (rec.x >> 26 & 1);
       } else if (kind == 2) {
         const V3 n = {s1[3 + 2], s1[3 + 5], s1[3 + 8]};
@@ -1247,10 +1255,11 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
   const int depth = t.lane[TPI_DEPTH * TP_LPE + l], jnt = t.lane[TPI_JNT * TP_LPE + l];
   const int root = t.lane[TPI_ROOT * TP_LPE + l], act = t.lane[TPI_ACT * TP_LPE + l];
   const int eq_own = t.lane[TPI_EQ_OWN * TP_LPE + l], eq_pos = t.lane[TPI_EQ_POS * TP_LPE + l];
-  const int eq_other_raw = lane_ref(TPI_EQ_OTHER), eq_src_raw = lane_ref(TPI_EQ_SRC);
+  const int eq_src_raw = t.lane[TPI_EQ_SRC * TP_LPE + l];
   const int dd_raw = t.lane[TPI_DD * TP_LPE + l];
-  const int eq_other_sa = eq_other_raw >= 0 ? eq_other_raw : self_sa;
-  const int eq_src_sa = eq_src_raw >= 0 ? eq_src_raw : self_sa;
+  const int base4 = base * 4;
+  const int eq_other_sa = base4 + t.lane[TPI_SA_EQO * TP_LPE + l];
+  const int eq_src_sa = base4 + t.lane[TPI_SA_EQS * TP_LPE + l];
   const bool has_dof = jnt >= 0, is_src = eq_src_raw >= 0;
   const bool isb = l < m.nbody && l > 0;
   const int b = l < m.nbody ? l : 0, j = has_dof ? jnt : 0, ja = act >= 0 ? act : 0;
@@ -1265,15 +1274,10 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
   if constexpr (CON) ncand_pre = AT(cd.ncand, 0);
   TpCtx c;
   c.self_sa = self_sa; c.zero_sa = (base + TP_LPE - 1) * 4; c.dd = has_dof ? dd_raw : 0; c.maxdd = t.maxdd; c.tbl = (tp_lds_ptr)tbl;
-  c.dchild0 = lane_ref(TPI_DCHILD);
-  if (c.dchild0 < 0) c.dchild0 = (base + TP_LPE - 1) * 4;
-  int bchild0 = lane_ref(TPI_BCHILD);
-  if (bchild0 < 0) bchild0 = (base + TP_LPE - 1) * 4;
+  c.dchild0 = base4 + t.lane[TPI_SA_DC0 * TP_LPE + l];
+  const int bchild0 = base4 + t.lane[TPI_SA_BC0 * TP_LPE + l];
 #pragma unroll
-  for (int a = 0; a < TP_MAXD; a++) {
-    const int v = lane_ref(TPI_ANC + a);
-    c.anc_sa[a] = v >= 0 ? v : self_sa;
-  }
+  for (int a = 0; a < TP_MAXD; a++) c.anc_sa[a] = base4 + t.lane[(TPI_SA_ANC + a) * TP_LPE + l];
   c.top_sa = self_sa;
 #pragma unroll
   for (int a = 1; a < TP_MAXD; a++)
@@ -1281,17 +1285,10 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
 #pragma unroll
   for (int D = 0; D < TP_MAXD + 2; D++) c.nchild[D] = t.lvl_dchild[D];
   {
-    const int zl = base + TP_LPE - 1;  // the environment's zero lane stands for "no child"
-    for (int r = 0; r < 2 * TPL_CROWS; r++) {
-      const int first = (r < TPL_CROWS ? TPI_BCHILD : TPI_DCHILD) + 1 + 4 * (r % TPL_CROWS);
-      int w = 0;
-      for (int k = 0; k < 4; k++) {
-        const int ch = 1 + 4 * (r % TPL_CROWS) + k;
-        const int v = ch < TP_MAXC ? t.lane[(first + k) * TP_LPE + l] : -1;
-        w |= (v >= 0 ? base + v : zl) << (8 * k);
-      }
-      tbl[r * 64 + tid] = w;
-    }
+    // child words from the host (lane bytes relative to the environment's first lane; every byte gets the half's offset)
+    const int bb = base * 0x01010101;
+#pragma unroll
+    for (int r = 0; r < 2 * TPL_CROWS; r++) tbl[r * 64 + tid] = t.lane[(TPI_CW + r) * TP_LPE + l] + bb;
   }
   tbl[TPL_ANCMASK * 64 + tid] = t.lane[TPI_ANCMASK * TP_LPE + l];
 #if TP_LPE == 64
@@ -2004,16 +2001,34 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
               if (lo == j1) y = y1;
               AB[lo] = tp_d2{a, b};
               tp_wave_sync();
-              // four rows per round of broadcast reads
+              // TPC_ROWB rows per round of broadcast reads, the next round's reads issued before this round's FMAs
+#ifndef TPC_ROWB
+#define TPC_ROWB 4
+#endif
+              {
+                tp_d2 cur[TPC_ROWB], nxt[TPC_ROWB];
 #pragma unroll
-              for (int i0 = 0; i0 < j0; i0 += 4) {
-                tp_d2 ab[4];
+                for (int q = 0; q < TPC_ROWB; q++)
+                  if (q < j0) cur[q] = AB[q];
 #pragma unroll
-                for (int q = 0; q < 4; q++)
-                  if (i0 + q < j0) ab[q] = AB[i0 + q];
+                for (int i0 = 0; i0 < j0; i0 += TPC_ROWB) {
+#ifdef TPC_PREFETCH
 #pragma unroll
-                for (int q = 0; q < 4; q++)
-                  if (i0 + q < j0) h[i0 + q] = (h[i0 + q] - ab[q].x * a) - ab[q].y * b;
+                  for (int q = 0; q < TPC_ROWB; q++)
+                    if (i0 + TPC_ROWB + q < j0) nxt[q] = AB[i0 + TPC_ROWB + q];
+#endif
+#pragma unroll
+                  for (int q = 0; q < TPC_ROWB; q++)
+                    if (i0 + q < j0) h[i0 + q] = (h[i0 + q] - cur[q].x * a) - cur[q].y * b;
+#ifdef TPC_PREFETCH
+#pragma unroll
+                  for (int q = 0; q < TPC_ROWB; q++) cur[q] = nxt[q];
+#else
+#pragma unroll
+                  for (int q = 0; q < TPC_ROWB; q++)
+                    if (i0 + TPC_ROWB + q < j0) cur[q] = AB[i0 + TPC_ROWB + q];
+#endif
+                }
               }
               tp_wave_sync();
             }
