@@ -1856,10 +1856,10 @@ extern "C" int bs_collision_stats(bs_sim* s, uint64_t out[3], int reset) {
 #endif
 #ifdef NP_TIMING
   {
-    uint64_t t[20];
+    uint64_t t[24];
     HIPCHK(hipMemcpy(t, s->cd.stat + 8, sizeof t, hipMemcpyDeviceToHost));
     fprintf(stderr, "np_timing");
-    for (int q = 0; q < 20; q++) fprintf(stderr, " %llu", (unsigned long long)t[q]);
+    for (int q = 0; q < 24; q++) fprintf(stderr, " %llu", (unsigned long long)t[q]);
     fprintf(stderr, "\n");
     HIPCHK(hipMemset(s->cd.stat + 8, 0, sizeof t));
   }

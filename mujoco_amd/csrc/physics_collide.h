@@ -69,8 +69,10 @@ struct ColModel {
 };
 
 // cube-map direction bins: 6 faces x BS_SG x BS_SG
+#ifndef BS_SG
 #define BS_SG 64  // measured at 65 536 envs: 16 -> 28.5, 32 -> 29.3, 48 -> 29.6, 64 -> 29.8 M env-steps/s (climbs start nearer their end;
                   // 19 MB of start records per device for the hand's 24 hulls)
+#endif
 #define BS_NSTART (6 * BS_SG * BS_SG)
 #define BS_CAND_K 4      // candidate records per bin held in line (98 % of the hand's bins have no more)
 #define BS_CAND_MAX (1 << 20)  // no cap in practice (a flat cap's normal sits in one bin with the cap's whole rim)
@@ -183,6 +185,10 @@ __device__ __forceinline__ int rec_id(double w) { return __double2loint(w) & 0xF
 __device__ __forceinline__ int rec_deg(double w) { return (__double2loint(w) >> 20) & 0xFFF; }
 __device__ __forceinline__ int rec_k0(double w) { return __double2hiint(w); }
 
+// converged pairs of the persistent narrowphase that run mpr_finish together (measured at 65 536 envs)
+#ifndef NP_FIN_BATCH
+#define NP_FIN_BATCH 6
+#endif
 #ifndef MD_BATCH
 #define MD_BATCH 8  // neighbour records per trip of md_support's climb loop
 #endif
@@ -403,8 +409,45 @@ __device__ __forceinline__ void mpr_begin(MprState& M, const V3& c1, const V3& c
   M.d = normalized(neg(M.p0));
   M.pk = 0;
 }
+// Last part of the refinement: penetration depth, direction and contact position from the final portal.  A function of
+// its own so that the persistent narrowphase can run it for a BATCH of lanes: inside mpr_step it executed on almost every
+// trip of the support loop for the two or three lanes whose pair had just converged (~350 instructions at 3 of 64 lanes:
+// the largest single loss of the kernel, round 3).
+__device__ __forceinline__ void mpr_finish(const MprState& M, const V3& c1, const V3& c2, double& depth, V3& dir, V3& pos) {
+  const SptS* P = M.P - 1;  // P[1..3]
+  const V3& p0 = M.p0;
+  const V3& d = M.d;
+  const V3 origin = {0, 0, 0};
+  V3 w;
+  depth = sqrt(origin_tri_dist2(P[1].v, P[2].v, P[3].v, w));
+  dir = c_is_zero(depth) ? origin : normalized(w);
+  // position from barycentric coordinates of the origin in the portal tetrahedron
+  double bb[4];
+  bb[0] = dot(cross(P[1].v, P[2].v), P[3].v);
+  bb[1] = dot(cross(P[3].v, P[2].v), p0);
+  bb[2] = dot(cross(p0, P[1].v), P[3].v);
+  bb[3] = dot(cross(P[2].v, P[1].v), p0);
+  double sum = bb[0] + bb[1] + bb[2] + bb[3];
+  if (c_is_zero(sum) || sum < 0) {
+    bb[0] = 0;
+    bb[1] = dot(cross(P[2].v, P[3].v), d);
+    bb[2] = dot(cross(P[3].v, P[1].v), d);
+    bb[3] = dot(cross(P[1].v, P[2].v), d);
+    sum = bb[1] + bb[2] + bb[3];
+  }
+  const double inv = 1.0 / sum;
+  V3 p1 = {0 + bb[0] * c1.x, 0 + bb[0] * c1.y, 0 + bb[0] * c1.z}, p2 = {0 + bb[0] * c2.x, 0 + bb[0] * c2.y, 0 + bb[0] * c2.z};
+#pragma unroll
+  for (int i = 1; i < 4; i++) {
+    p1.x += bb[i] * P[i].v1.x; p1.y += bb[i] * P[i].v1.y; p1.z += bb[i] * P[i].v1.z;
+    p2.x += bb[i] * (P[i].v1.x - P[i].v.x); p2.y += bb[i] * (P[i].v1.y - P[i].v.y); p2.z += bb[i] * (P[i].v1.z - P[i].v.z);
+  }
+  pos = {0.5 * (p1.x * inv + p2.x * inv), 0.5 * (p1.y * inv + p2.y * inv), 0.5 * (p1.z * inv + p2.z * inv)};
+}
 // consumes the support point `s` of direction M.d; returns 0 = query M.d again, 1 = the inflated
 // hulls intersect (depth, dir = unit normal obj1 -> obj2, pos filled), 2 = they do not
+// DEFER: 3 = the portal has converged, the caller owes the pair a call of mpr_finish
+template <bool DEFER = false>
 __device__ __forceinline__ int mpr_step(MprState& M, const Spt& sfull, const V3& c1, const V3& c2, double tol, int maxit,
                                         double& depth, V3& dir, V3& pos, int& iters) {
   SptS* P = M.P - 1;  // P[1..3]
@@ -467,31 +510,10 @@ __device__ __forceinline__ int mpr_step(MprState& M, const Spt& sfull, const V3&
       const double y = dot(s.v, d);
       if (!(c_is_zero(y) || y > 0) || rt) return 2;
     } else if (rt || it > maxit) {
-      V3 w;
-      depth = sqrt(origin_tri_dist2(P[1].v, P[2].v, P[3].v, w));
-      dir = c_is_zero(depth) ? origin : normalized(w);
-      // position from barycentric coordinates of the origin in the portal tetrahedron
-      double bb[4];
-      bb[0] = dot(cross(P[1].v, P[2].v), P[3].v);
-      bb[1] = dot(cross(P[3].v, P[2].v), p0);
-      bb[2] = dot(cross(p0, P[1].v), P[3].v);
-      bb[3] = dot(cross(P[2].v, P[1].v), p0);
-      double sum = bb[0] + bb[1] + bb[2] + bb[3];
-      if (c_is_zero(sum) || sum < 0) {
-        bb[0] = 0;
-        bb[1] = dot(cross(P[2].v, P[3].v), d);
-        bb[2] = dot(cross(P[3].v, P[1].v), d);
-        bb[3] = dot(cross(P[1].v, P[2].v), d);
-        sum = bb[1] + bb[2] + bb[3];
-      }
-      const double inv = 1.0 / sum;
-      V3 p1 = {0 + bb[0] * c1.x, 0 + bb[0] * c1.y, 0 + bb[0] * c1.z}, p2 = {0 + bb[0] * c2.x, 0 + bb[0] * c2.y, 0 + bb[0] * c2.z};
-#pragma unroll
-      for (int i = 1; i < 4; i++) {
-        p1.x += bb[i] * P[i].v1.x; p1.y += bb[i] * P[i].v1.y; p1.z += bb[i] * P[i].v1.z;
-        p2.x += bb[i] * (P[i].v1.x - P[i].v.x); p2.y += bb[i] * (P[i].v1.y - P[i].v.y); p2.z += bb[i] * (P[i].v1.z - P[i].v.z);
-      }
-      pos = {0.5 * (p1.x * inv + p2.x * inv), 0.5 * (p1.y * inv + p2.y * inv), 0.5 * (p1.z * inv + p2.z * inv)};
+      // the portal has reached the surface: depth, normal and position (mpr_finish).  DEFER: the caller runs
+      // mpr_finish itself, for several lanes at once — M is complete (the support point of this call is not used)
+      if (DEFER) return 3;
+      mpr_finish(M, c1, c2, depth, dir, pos);
       return 1;
     }
     expand_portal(P, p0, s);
@@ -892,7 +914,7 @@ __device__ inline void col_narrow_persistent(const ColModel& cm, const DevData& 
       else hi = mid;
     }
   }
-  bool busy = false, plane = false;
+  bool busy = false, plane = false, pend = false;
   long e = 0;
   int slot = 0, iters = 0;
   double margin = 0;
@@ -982,7 +1004,26 @@ __device__ inline void col_narrow_persistent(const ColModel& cm, const DevData& 
       for (int q = 0; q < 6; q++) { const unsigned long long bq = __ballot(busy && st == q); NPT(8 + q, bq != 0) NPT(14 + q, __popcll(bq)) }
     }
 #endif
-    if (busy) {
+    // the candidate record of a finished item
+    auto put_record = [&](bool hit, double dist, const V3& pos, const V3& nrm) {
+      if (c.crec) {
+        CandRec* cr = c.crec + (size_t)e * cm.maxcand + slot;
+        cr->hit = hit ? 1 : 0;
+        if (hit) {
+          cr->dist = dist;
+          cr->pos[0] = pos.x; cr->pos[1] = pos.y; cr->pos[2] = pos.z;
+          cr->nrm[0] = nrm.x; cr->nrm[1] = nrm.y; cr->nrm[2] = nrm.z;
+        }
+      } else {
+        AT(c.cand_hit, slot) = hit ? 1 : 0;
+        if (hit) {
+          AT(c.cand_dist, slot) = dist;
+          AT(c.cand_pos, 3 * slot) = pos.x; AT(c.cand_pos, 3 * slot + 1) = pos.y; AT(c.cand_pos, 3 * slot + 2) = pos.z;
+          AT(c.cand_nrm, 3 * slot) = nrm.x; AT(c.cand_nrm, 3 * slot + 1) = nrm.y; AT(c.cand_nrm, 3 * slot + 2) = nrm.z;
+        }
+      }
+    };
+    if (busy && !pend) {
 #ifdef NP_TIMING
       const Spt s = md_support(a, b, M.d, plane, np_t);
 #else
@@ -1001,36 +1042,38 @@ __device__ inline void col_narrow_persistent(const ColModel& cm, const DevData& 
         }
       } else {
         double depth = 0;
-        const int r = mpr_step(M, s, a.xpos, b.xpos, cm.mpr_tolerance, cm.mpr_iterations, depth, nrm, pos, iters);
-        fin = r != 0;
+        const int r = mpr_step<true>(M, s, a.xpos, b.xpos, cm.mpr_tolerance, cm.mpr_iterations, depth, nrm, pos, iters);
+        fin = r == 1 || r == 2;
+        pend = r == 3;  // converged: depth, normal and position are computed below, for several lanes at once
         if (r == 1 && !(nrm.x == 0 && nrm.y == 0 && nrm.z == 0)) { hit = true; dist = margin - depth; }
         if (fin) { acc[0] += 1; acc[1] += (unsigned)iters; }
       }
       if (fin) {
-        if (c.crec) {
-          CandRec* cr = c.crec + (size_t)e * cm.maxcand + slot;
-          cr->hit = hit ? 1 : 0;
-          if (hit) {
-            cr->dist = dist;
-            cr->pos[0] = pos.x; cr->pos[1] = pos.y; cr->pos[2] = pos.z;
-            cr->nrm[0] = nrm.x; cr->nrm[1] = nrm.y; cr->nrm[2] = nrm.z;
-          }
-        } else {
-          AT(c.cand_hit, slot) = hit ? 1 : 0;
-          if (hit) {
-            AT(c.cand_dist, slot) = dist;
-            AT(c.cand_pos, 3 * slot) = pos.x; AT(c.cand_pos, 3 * slot + 1) = pos.y; AT(c.cand_pos, 3 * slot + 2) = pos.z;
-            AT(c.cand_nrm, 3 * slot) = nrm.x; AT(c.cand_nrm, 3 * slot + 1) = nrm.y; AT(c.cand_nrm, 3 * slot + 2) = nrm.z;
-          }
-        }
+        put_record(hit, dist, pos, nrm);
         busy = false;
+      }
+    }
+    // ---- converged pairs wait (their lanes idle) until NP_FIN_BATCH of them can run mpr_finish together, or nothing else is left to do
+    {
+      const unsigned long long pb = __ballot(pend);
+      if (pb && (__popcll(pb) >= NP_FIN_BATCH || !__ballot(busy && !pend))) {
+        NPT(20, 1) NPT(21, __popcll(pb))
+        if (pend) {
+          double depth = 0;
+          V3 pos = {0, 0, 0}, nrm = {0, 0, 0};
+          mpr_finish(M, a.xpos, b.xpos, depth, nrm, pos);
+          const bool hit = !(nrm.x == 0 && nrm.y == 0 && nrm.z == 0);
+          acc[0] += 1; acc[1] += (unsigned)iters;
+          put_record(hit, margin - depth, pos, nrm);
+          busy = false; pend = false;
+        }
       }
     }
     NPT_CLK(2)
   }
 #ifdef NP_TIMING
   if (lane == 0 && c.stat)
-    for (int k = 0; k < 20; k++) atomicAdd(c.stat + 8 + k, np_t[k]);
+    for (int k = 0; k < 24; k++) atomicAdd(c.stat + 8 + k, np_t[k]);
 #endif
 }
 
