@@ -72,6 +72,10 @@ def lib():
         raise BatchSimError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(there is no CPU fallback)")
+    # torch first: it ships its own HIP runtime, and the zero-copy views need torch and the library to share ONE runtime.
+    # Loaded the other way round (libbatchsim.so pulls in /opt/rocm's libamdhip64 before torch loads its bundled copy)
+    # torch's lazy initialisation reports "No HIP GPUs are available".
+    import torch  # noqa: F401
     L = C.CDLL(LIB_PATH)
     vp = C.c_void_p
     L.bs_version.restype = C.c_int

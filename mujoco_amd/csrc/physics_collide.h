@@ -70,11 +70,18 @@ struct ColModel {
 
 // cube-map direction bins: 6 faces x BS_SG x BS_SG
 #ifndef BS_SG
-#define BS_SG 64  // measured at 65 536 envs: 16 -> 28.5, 32 -> 29.3, 48 -> 29.6, 64 -> 29.8 M env-steps/s (climbs start nearer their end;
-                  // 19 MB of start records per device for the hand's 24 hulls)
+// Round 3, with the per-bin support candidates (hull_cand4): finer bins mean fewer bins that straddle the normal cones of
+// several vertices, i.e. fewer candidates to compare per support call and fewer calls that continue into the overflow
+// list.  Contacts at 65 536 envs, (bins per face edge, records held in line): (16, 4) 38.3, (32, 4) 42.4, (64, 4) 44.9,
+// (96, 4) 46.1, (128, 4) 46.8, (96, 2) 47.0, (128, 3) 47.7, (128, 2) 47.9, (192, 2) 48.2, (256, 2) 48.2 M env-steps/s.
+// (128, 2): 6.3 MB of candidate records per hull, 151 MB per device for the hand's 24 hulls, 1.5 s to build.
+// (Round 2, hill climbing from a start vertex per bin: 16 -> 28.5, 32 -> 29.3, 48 -> 29.6, 64 -> 29.8 M.)
+#define BS_SG 128
 #endif
 #define BS_NSTART (6 * BS_SG * BS_SG)
-#define BS_CAND_K 4      // candidate records per bin held in line (98 % of the hand's bins have no more)
+#ifndef BS_CAND_K
+#define BS_CAND_K 2      // candidate records per bin held in line (bins with more continue through hull_more4)
+#endif
 #define BS_CAND_MAX (1 << 20)  // no cap in practice (a flat cap's normal sits in one bin with the cap's whole rim)
 __host__ __device__ inline int dir_bin(double x, double y, double z) {
   const double ax = x < 0 ? -x : x, ay = y < 0 ? -y : y, az = z < 0 ? -z : z;
