@@ -1381,7 +1381,7 @@ extern "C" int bs_sim_create(const bs_model* const* models, int n_models, const 
     if (!s->use_tpc) np = 1;
     while (np > 1 && (n_envs < 128L * np || split_chunk(n_envs, np) * (np - 1) >= n_envs)) np--;
     s->split = np;
-    if (np >= 3 && !getenv("BS_NL_GRID")) s->nl_grid = 1024;  // three narrowphase launches share the machine
+    if (np >= 3 && !getenv("BS_NL_GRID")) s->nl_grid = 1408;  // three narrowphase launches share the machine (round 3, after the support tables: 768 -> 47.6, 1024 -> 48.0, 1280 -> 48.8, 1536 -> 48.7, 2048 -> 48.4 M env-steps/s at 65 536 envs)
     if (s->split > 1) {
       HIPCHK_S(hipEventCreateWithFlags(&s->fork_ev, hipEventDisableTiming));
       for (int q = 0; q < s->split - 1; q++) {
