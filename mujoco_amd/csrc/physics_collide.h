@@ -453,6 +453,99 @@ __device__ __forceinline__ void mpr_finish(const MprState& M, const V3& c1, cons
 }
 // consumes the support point `s` of direction M.d; returns 0 = query M.d again, 1 = the inflated
 // hulls intersect (depth, dir = unit normal obj1 -> obj2, pos filled), 2 = they do not
+// Two forms of the step, same arithmetic per lane.  MPR_UNIFIED (opt-in, -DMPR_UNIFIED): written at the end of round 3,
+// compiles (158 VGPRs, no scratch) but has NOT run on a GPU — access to the pool closed before its first test — so
+// the default stays the branchy form every parity test has passed with.
+#ifdef MPR_UNIFIED
+// DEFER: 3 = the portal has converged, the caller owes the pair a call of mpr_finish
+// Round 3: ONE instruction stream for all phases.  The phases used to be four branches — store the support point,
+// test it, form the next direction — that a wavefront with lanes in every phase (the usual case in the persistent
+// narrowphase) executed one after the other, each with its own LDS round trips and its own normalisation chain; the
+// kernel is latency-bound (~24 000 cycles per trip of the support loop for ~1 000 instructions), so the four serial
+// chains were the cost.  Every lane now reads the portal once, evaluates the tests of its phase next to the other
+// phases' (unused results are discarded), stores the support point into the slot its phase selects, and forms the next
+// direction with ONE cross product and ONE normalisation whose operands are selected by phase:
+//   state 0:             d = p0 x P1                  = (p0 - 0) x (P1 - 0)
+//   state 1, 2 (again):  d = (P1 - p0) x (P2 - p0)
+//   state 2 (done), 3, 4: d = (P2 - P1) x (P3 - P1)   (portal_dir)
+// Per lane the arithmetic is the branches' (x - 0 is x, bit for bit), so the contact sets do not move.
+template <bool DEFER = false>
+__device__ __forceinline__ int mpr_step(MprState& M, const Spt& sfull, const V3& c1, const V3& c2, double tol, int maxit,
+                                        double& depth, V3& dir, V3& pos, int& iters) {
+  SptS* P = M.P - 1;  // P[1..3]
+  const V3 sv = sfull.v, sv1 = sfull.v1;
+  const V3 p0 = M.p0, d = M.d;
+  V3 P1v = P[1].v, P2v = P[2].v, P3v = P[3].v;  // (phases 0 / 1: what the slots still hold of the lane's last pair — unused)
+  int state = M.pk & 7, guard = (M.pk >> 3) & 255, it = M.pk >> 11;
+  const V3 origin = {0, 0, 0};
+  // ---- the support point against the query direction
+  const double dt = dot(sv, d);
+  const bool refine = state >= 3;
+  if (refine) iters++;
+  const double m3 = fmin(fmin(dt - dot(P1v, d), dt - dot(P2v, d)), dt - dot(P3v, d));
+  const bool rt = c_is_eq(m3, tol) || m3 < tol;  // reach_tol(P, s, d, tol)
+  if (!refine) {
+    if (c_is_zero(dt) || dt < 0) return 2;
+  } else if (state == 3) {
+    if (!(c_is_zero(dt) || dt > 0) || rt) return 2;
+  } else if (rt || it > maxit) {
+    // the portal has reached the surface: depth, normal and position (mpr_finish).  DEFER: the caller runs
+    // mpr_finish itself, for several lanes at once — M is complete (the support point of this call is not used)
+    if (DEFER) return 3;
+    mpr_finish(M, c1, c2, depth, dir, pos);
+    return 1;
+  }
+  // ---- which portal point the support point replaces
+  //   state 2 (discovery): point 2 or 1 while the portal does not enclose the origin ray, else point 3
+  const double x1 = dot(cross(P1v, sv), p0), x2 = dot(cross(sv, P2v), p0);
+  const bool c1s = x1 < 0 && !c_is_zero(x1), c2s = x2 < 0 && !c_is_zero(x2);
+  const bool cont = state == 2 && (c1s || c2s);
+  //   state 3 / 4: expand_portal
+  const V3 v4v0 = cross(sv, p0);
+  const bool t1 = dot(P1v, v4v0) > 0, t2 = dot(P2v, v4v0) > 0, t3 = dot(P3v, v4v0) > 0;
+  const int tgt34 = t1 ? (t2 ? 1 : 3) : (t3 ? 2 : 1);
+  const int tgt2 = c1s ? 2 : (c2s ? 1 : 3);
+  const int tgt = state == 0 ? 1 : (state == 1 ? 2 : (state == 2 ? tgt2 : tgt34));
+  P[tgt] = SptS{sv, sv1};
+  if (tgt == 1) P1v = sv;
+  if (tgt == 2) P2v = sv;
+  if (tgt == 3) P3v = sv;
+  if (refine) it++;
+  if (cont && ++guard > 100) return 2;
+  if (state == 3 && it > maxit + 1) return 2;
+  // ---- next query direction
+  const bool clsX = state == 0, clsY = state == 1 || cont;
+  const V3 A = clsX ? p0 : (clsY ? P1v : P2v), B = clsX ? P1v : (clsY ? P2v : P3v), C = clsX ? origin : (clsY ? p0 : P1v);
+  const V3 raw = cross(sub(A, C), sub(B, C));
+  if (clsX && c_is_zero(dot(raw, raw))) {
+    pos = {0.5 * (sfull.v1.x + sfull.v2.x), 0.5 * (sfull.v1.y + sfull.v2.y), 0.5 * (sfull.v1.z + sfull.v2.z)};
+    if (v_eq(sv, origin)) { depth = 0; dir = origin; return 1; }  // touching
+    depth = sqrt(dot(sv, sv));
+    dir = normalized(sv);
+    return 1;  // origin on the segment v0-v1
+  }
+  V3 dn = normalized(raw);
+  if (state == 1) {
+    if (dot(dn, p0) > 0) {
+      swap_spt(P[1], P[2]);
+      dn = neg(dn);
+    }
+    guard = 1;
+    state = 2;
+  } else if (state == 0) {
+    state = 1;
+  } else if (!cont && state != 4) {
+    // discovery finished (state 2) or refinement (state 3): does the portal enclose the origin ray?
+    if (state == 2) it = 0;
+    const double x = dot(dn, P1v);
+    if (c_is_zero(x) || x > 0) { it = 0; state = 4; }
+    else state = 3;
+  }
+  M.d = dn;
+  M.pk = state | (guard << 3) | (it << 11);
+  return 0;
+}
+#else
 // DEFER: 3 = the portal has converged, the caller owes the pair a call of mpr_finish
 template <bool DEFER = false>
 __device__ __forceinline__ int mpr_step(MprState& M, const Spt& sfull, const V3& c1, const V3& c2, double tol, int maxit,
@@ -545,6 +638,7 @@ __device__ __forceinline__ int mpr_step(MprState& M, const Spt& sfull, const V3&
   M.pk = state | (guard << 3) | (it << 11);
   return 0;
 }
+#endif
 // returns true when the inflated hulls intersect; fills depth, dir (unit, obj1 -> obj2), pos
 // `Mp`: where the state lives.  The portal update copies structs through selected pointers, so the
 // state is a memory object whatever one does; the kernels hand in a slot of LDS (one per lane,
