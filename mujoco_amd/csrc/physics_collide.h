@@ -153,23 +153,27 @@ __host__ __device__ inline long col_items_base(long env0, int range, int maxcand
   return (env0 + (long)range * 2 * BS_NSUB) * (long)maxcand;
 }
 
-__device__ __forceinline__ bool c_is_zero(double x) { return fabs(x) < BS_CCD_EPS; }
-__device__ __forceinline__ bool c_is_eq(double a, double b) {
+__host__ __device__ __forceinline__ bool c_is_zero(double x) { return fabs(x) < BS_CCD_EPS; }
+__host__ __device__ __forceinline__ bool c_is_eq(double a, double b) {
   const double ab = fabs(a - b);
   if (ab < BS_CCD_EPS) return true;
   return ab < BS_CCD_EPS * fmax(fabs(a), fabs(b));
 }
-__device__ __forceinline__ double dot(const V3& a, const V3& b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
-__device__ __forceinline__ V3 sub(const V3& a, const V3& b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
-__device__ __forceinline__ V3 sub3(const V3& a, const V3& b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
-__device__ __forceinline__ V3 neg(const V3& a) { return {-a.x, -a.y, -a.z}; }
+__host__ __device__ __forceinline__ double dot(const V3& a, const V3& b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__host__ __device__ __forceinline__ V3 sub(const V3& a, const V3& b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__host__ __device__ __forceinline__ V3 sub3(const V3& a, const V3& b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__host__ __device__ __forceinline__ V3 neg(const V3& a) { return {-a.x, -a.y, -a.z}; }
 // a / |a|: v_rsq_f64 refined by Goldschmidt rounds and three multiplications (12 + 3 VALU instructions; the IEEE
 // sqrt and three IEEE divisions were ~100, and MPR normalises a direction or two per portal step).  Within an ulp
 // or two of the IEEE quotient; squared lengths outside the normal range take the IEEE path.
-__device__ __forceinline__ V3 normalized(const V3& a) {
+__host__ __device__ __forceinline__ V3 normalized(const V3& a) {
   const double d = dot(a, a);
   if (d > 1e-280 && d < 1e280) {
+#ifdef __HIP_DEVICE_COMPILE__
     const double y = __builtin_amdgcn_rsq(d);
+#else
+    const double y = 1.0 / sqrt(d);  // host compile (tests/host_mpr: the two forms of mpr_step against each other on the CPU)
+#endif
     double g = d * y, h = 0.5 * y;
     double r = fma(-h, g, 0.5);
     g = fma(g, r, g); h = fma(h, r, h);
@@ -184,7 +188,7 @@ __device__ __forceinline__ V3 normalized(const V3& a) {
   if (n > 0) return {a.x / n, a.y / n, a.z / n};
   return a;
 }
-__device__ __forceinline__ bool v_eq(const V3& a, const V3& b) {
+__host__ __device__ __forceinline__ bool v_eq(const V3& a, const V3& b) {
   return c_is_eq(a.x, b.x) && c_is_eq(a.y, b.y) && c_is_eq(a.z, b.z);
 }
 
@@ -342,15 +346,15 @@ __device__ inline Spt md_support(CObj& a, CObj& b, const V3& dir, bool only_b = 
   s.v = sub(s.v1, s.v2);
   return s;
 }
-__device__ __forceinline__ V3 portal_dir(const SptS* P) {
+__host__ __device__ __forceinline__ V3 portal_dir(const SptS* P) {
   return normalized(cross(sub(P[2].v, P[1].v), sub(P[3].v, P[1].v)));
 }
-__device__ __forceinline__ bool reach_tol(const SptS* P, const SptS& v4, const V3& dir, double tol) {
+__host__ __device__ __forceinline__ bool reach_tol(const SptS* P, const SptS& v4, const V3& dir, double tol) {
   const double dv4 = dot(v4.v, dir);
   const double m = fmin(fmin(dv4 - dot(P[1].v, dir), dv4 - dot(P[2].v, dir)), dv4 - dot(P[3].v, dir));
   return c_is_eq(m, tol) || m < tol;
 }
-__device__ __forceinline__ void expand_portal(SptS* P, const V3& p0, const SptS& v4) {
+__host__ __device__ __forceinline__ void expand_portal(SptS* P, const V3& p0, const SptS& v4) {
   const V3 v4v0 = cross(v4.v, p0);
   if (dot(P[1].v, v4v0) > 0) {
     if (dot(P[2].v, v4v0) > 0) P[1] = v4;
@@ -360,7 +364,7 @@ __device__ __forceinline__ void expand_portal(SptS* P, const V3& p0, const SptS&
     else P[1] = v4;
   }
 }
-__device__ inline double origin_tri_dist2(const V3& a, const V3& b, const V3& c, V3& w) {
+__host__ __device__ inline double origin_tri_dist2(const V3& a, const V3& b, const V3& c, V3& w) {
   const V3 ab = sub(b, a), ac = sub(c, a), ap = neg(a);
   const double d1 = dot(ab, ap), d2 = dot(ac, ap);
   if (d1 <= 0 && d2 <= 0) { w = a; return dot(w, w); }
@@ -397,19 +401,19 @@ __device__ inline double origin_tri_dist2(const V3& a, const V3& b, const V3& c,
 // portal, refine until the portal encloses the origin ray, push the portal to the surface) are the
 // values of `state`; the caller owns the loop around the support call, so the lanes of a
 // wavefront stay converged on the expensive part whatever phase each one is in.
-__device__ __forceinline__ void swap3(V3& a, V3& b) {
+__host__ __device__ __forceinline__ void swap3(V3& a, V3& b) {
   const double x = a.x, y = a.y, z = a.z;
   a.x = b.x; a.y = b.y; a.z = b.z;
   b.x = x; b.y = y; b.z = z;
 }
-__device__ __forceinline__ void swap_spt(SptS& a, SptS& b) { swap3(a.v, b.v); swap3(a.v1, b.v1); }
+__host__ __device__ __forceinline__ void swap_spt(SptS& a, SptS& b) { swap3(a.v, b.v); swap3(a.v1, b.v1); }
 struct MprState {
   V3 p0;     // portal point 0 = centre difference (its two support points are the geom centres)
   SptS P[3]; // portal points 1..3
   V3 d;           // direction of the next support query
   int pk;         // state (bits 0-2) | guard (3-10) | it (11-): one word, so a lane's slot is 200 bytes
 };
-__device__ __forceinline__ void mpr_begin(MprState& M, const V3& c1, const V3& c2) {
+__host__ __device__ __forceinline__ void mpr_begin(MprState& M, const V3& c1, const V3& c2) {
   const V3 origin = {0, 0, 0};
   M.p0 = sub(c1, c2);
   if (v_eq(M.p0, origin)) M.p0 = {BS_CCD_EPS * 10, 0, 0};
@@ -420,7 +424,7 @@ __device__ __forceinline__ void mpr_begin(MprState& M, const V3& c1, const V3& c
 // its own so that the persistent narrowphase can run it for a BATCH of lanes: inside mpr_step it executed on almost every
 // trip of the support loop for the two or three lanes whose pair had just converged (~350 instructions at 3 of 64 lanes:
 // the largest single loss of the kernel, round 3).
-__device__ __forceinline__ void mpr_finish(const MprState& M, const V3& c1, const V3& c2, double& depth, V3& dir, V3& pos) {
+__host__ __device__ __forceinline__ void mpr_finish(const MprState& M, const V3& c1, const V3& c2, double& depth, V3& dir, V3& pos) {
   const SptS* P = M.P - 1;  // P[1..3]
   const V3& p0 = M.p0;
   const V3& d = M.d;
@@ -455,7 +459,8 @@ __device__ __forceinline__ void mpr_finish(const MprState& M, const V3& c1, cons
 // hulls intersect (depth, dir = unit normal obj1 -> obj2, pos filled), 2 = they do not
 // Two forms of the step, same arithmetic per lane.  MPR_UNIFIED (opt-in, -DMPR_UNIFIED): written at the end of round 3,
 // compiles (158 VGPRs, no scratch) but has NOT run on a GPU — access to the pool closed before its first test — so
-// the default stays the branchy form every parity test has passed with.
+// the default stays the branchy form every parity test has passed with.  On the CPU the two forms agree bit for bit:
+// both are host-callable, tests/test_mpr_forms.py compiles each into a host library (tests/host_mpr/) and compares them.
 #ifdef MPR_UNIFIED
 // DEFER: 3 = the portal has converged, the caller owes the pair a call of mpr_finish
 // Round 3: ONE instruction stream for all phases.  The phases used to be four branches — store the support point,
@@ -470,7 +475,7 @@ __device__ __forceinline__ void mpr_finish(const MprState& M, const V3& c1, cons
 //   state 2 (done), 3, 4: d = (P2 - P1) x (P3 - P1)   (portal_dir)
 // Per lane the arithmetic is the branches' (x - 0 is x, bit for bit), so the contact sets do not move.
 template <bool DEFER = false>
-__device__ __forceinline__ int mpr_step(MprState& M, const Spt& sfull, const V3& c1, const V3& c2, double tol, int maxit,
+__host__ __device__ __forceinline__ int mpr_step(MprState& M, const Spt& sfull, const V3& c1, const V3& c2, double tol, int maxit,
                                         double& depth, V3& dir, V3& pos, int& iters) {
   SptS* P = M.P - 1;  // P[1..3]
   const V3 sv = sfull.v, sv1 = sfull.v1;
@@ -548,7 +553,7 @@ __device__ __forceinline__ int mpr_step(MprState& M, const Spt& sfull, const V3&
 #else
 // DEFER: 3 = the portal has converged, the caller owes the pair a call of mpr_finish
 template <bool DEFER = false>
-__device__ __forceinline__ int mpr_step(MprState& M, const Spt& sfull, const V3& c1, const V3& c2, double tol, int maxit,
+__host__ __device__ __forceinline__ int mpr_step(MprState& M, const Spt& sfull, const V3& c1, const V3& c2, double tol, int maxit,
                                         double& depth, V3& dir, V3& pos, int& iters) {
   SptS* P = M.P - 1;  // P[1..3]
   const SptS s = {sfull.v, sfull.v1};

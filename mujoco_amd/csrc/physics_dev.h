@@ -89,11 +89,11 @@ __device__ __forceinline__ M3 q2m(const Q4& q) {
   R.a[6] = 2 * (q13 - q02); R.a[7] = 2 * (q23 + q01);
   return R;
 }
-__device__ __forceinline__ V3 mrot(const M3& R, const V3& v) {
+__host__ __device__ __forceinline__ V3 mrot(const M3& R, const V3& v) {
   return {R.a[0] * v.x + R.a[1] * v.y + R.a[2] * v.z, R.a[3] * v.x + R.a[4] * v.y + R.a[5] * v.z,
           R.a[6] * v.x + R.a[7] * v.y + R.a[8] * v.z};
 }
-__device__ __forceinline__ V3 cross(const V3& a, const V3& b) {
+__host__ __device__ __forceinline__ V3 cross(const V3& a, const V3& b) {
   return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
 }
 __device__ __forceinline__ V3 ld3(const double* p) { return {p[0], p[1], p[2]}; }
