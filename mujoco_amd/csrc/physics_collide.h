@@ -457,11 +457,12 @@ __host__ __device__ __forceinline__ void mpr_finish(const MprState& M, const V3&
 }
 // consumes the support point `s` of direction M.d; returns 0 = query M.d again, 1 = the inflated
 // hulls intersect (depth, dir = unit normal obj1 -> obj2, pos filled), 2 = they do not
-// Two forms of the step, same arithmetic per lane.  MPR_UNIFIED (opt-in, -DMPR_UNIFIED): written at the end of round 3,
-// compiles (158 VGPRs, no scratch) but has NOT run on a GPU — access to the pool closed before its first test — so
-// the default stays the branchy form every parity test has passed with.  On the CPU the two forms agree bit for bit:
-// both are host-callable, tests/test_mpr_forms.py compiles each into a host library (tests/host_mpr/) and compares them.
-#ifdef MPR_UNIFIED
+// Two forms of the step, same arithmetic per lane: the default is ONE instruction stream for all portal phases (round 3);
+// -DMPR_BRANCHY keeps the form of rounds 1-2 (one branch per phase).  tests/test_mpr_forms.py compiles both for the host
+// (tests/host_mpr/) and checks that they agree bit for bit, call by call; on the GPU every contact test passes with
+// either (89 of 89), the unified form is 1.7 % faster on the contact step (49.6 against 48.8 M env-steps/s at 65 536 envs)
+// and needs 158 VGPRs where the branchy one needs 182.
+#ifndef MPR_BRANCHY
 // DEFER: 3 = the portal has converged, the caller owes the pair a call of mpr_finish
 // Round 3: ONE instruction stream for all phases.  The phases used to be four branches — store the support point,
 // test it, form the next direction — that a wavefront with lanes in every phase (the usual case in the persistent
@@ -477,10 +478,12 @@ __host__ __device__ __forceinline__ void mpr_finish(const MprState& M, const V3&
 template <bool DEFER = false>
 __host__ __device__ __forceinline__ int mpr_step(MprState& M, const Spt& sfull, const V3& c1, const V3& c2, double tol, int maxit,
                                         double& depth, V3& dir, V3& pos, int& iters) {
-  SptS* P = M.P - 1;  // P[1..3]
+  // (portal points 1..3 are M.P[0..2]; no `M.P - 1` here: with a run-time index into a state held in private memory — the
+  // work-stealing kernel — the compiler put the NEGATIVE base offset into the scratch instruction's unsigned SGPR operand,
+  // an out-of-range address: the GPU fault of this form's first run)
   const V3 sv = sfull.v, sv1 = sfull.v1;
   const V3 p0 = M.p0, d = M.d;
-  V3 P1v = P[1].v, P2v = P[2].v, P3v = P[3].v;  // (phases 0 / 1: what the slots still hold of the lane's last pair — unused)
+  V3 P1v = M.P[0].v, P2v = M.P[1].v, P3v = M.P[2].v;  // (phases 0 / 1: what the slots still hold of the lane's last pair — unused)
   int state = M.pk & 7, guard = (M.pk >> 3) & 255, it = M.pk >> 11;
   const V3 origin = {0, 0, 0};
   // ---- the support point against the query direction
@@ -511,7 +514,7 @@ __host__ __device__ __forceinline__ int mpr_step(MprState& M, const Spt& sfull, 
   const int tgt34 = t1 ? (t2 ? 1 : 3) : (t3 ? 2 : 1);
   const int tgt2 = c1s ? 2 : (c2s ? 1 : 3);
   const int tgt = state == 0 ? 1 : (state == 1 ? 2 : (state == 2 ? tgt2 : tgt34));
-  P[tgt] = SptS{sv, sv1};
+  M.P[tgt - 1] = SptS{sv, sv1};
   if (tgt == 1) P1v = sv;
   if (tgt == 2) P2v = sv;
   if (tgt == 3) P3v = sv;
@@ -532,7 +535,7 @@ __host__ __device__ __forceinline__ int mpr_step(MprState& M, const Spt& sfull, 
   V3 dn = normalized(raw);
   if (state == 1) {
     if (dot(dn, p0) > 0) {
-      swap_spt(P[1], P[2]);
+      swap_spt(M.P[0], M.P[1]);
       dn = neg(dn);
     }
     guard = 1;

@@ -1,6 +1,6 @@
 // Test infrastructure (CPU): the product's MPR step functions (mujoco_amd/csrc/physics_collide.h: mpr_begin, mpr_step,
 // mpr_finish — __host__ __device__) compiled for the HOST, around a brute-force support function, so that the two forms
-// of mpr_step (default: one branch per portal phase; -DMPR_UNIFIED: one instruction stream) can be compared with each
+// of mpr_step (default: one instruction stream; -DMPR_BRANCHY: one branch per portal phase) can be compared with each
 // other, call by call, without a GPU.  Built twice by tests/test_mpr_forms.py (hipcc --cuda-host-only).
 #include "../../mujoco_amd/csrc/physics_collide.h"
 #include <cstring>

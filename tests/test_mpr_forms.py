@@ -1,5 +1,5 @@
 """CPU: the two forms of the product's mpr_step (mujoco_amd/csrc/physics_collide.h — default: one branch per portal
-phase; -DMPR_UNIFIED: one instruction stream with phase-selected operands) are the SAME function.  Both are
+phase, -DMPR_BRANCHY; the default: one instruction stream with phase-selected operands) are the SAME function.  Both are
 __host__ __device__; tests/host_mpr/mpr_host.hip wraps them, compiled for the host, around an exhaustive support
 search, and this test runs thousands of posed hull pairs through both and compares every call's return code, packed
 state word and next direction (a trace hash), the support-call and iteration counts, and depth / normal / position, bit for
@@ -23,7 +23,7 @@ def forms(tmp_path_factory):
         pytest.skip("hipcc not available")
     d = tmp_path_factory.mktemp("mpr")
     libs = {}
-    for name, flag in (("branchy", []), ("unified", ["-DMPR_UNIFIED"])):
+    for name, flag in (("branchy", ["-DMPR_BRANCHY"]), ("unified", [])):
         out = str(d / f"libmpr_{name}.so")
         subprocess.run([HIPCC, "-O2", "-std=c++17", "--cuda-host-only", "-fPIC", "-shared", "-Wno-unused-function", *flag,
                         "-o", out, os.path.join(ROOT, "tests", "host_mpr", "mpr_host.hip")], check=True, capture_output=True)
