@@ -649,6 +649,14 @@ static int model_image(bs_model* m, int device, const DeviceImage** out) {
   PUT_CI(mesh_vertadr, s.mesh_vertadr, s.nmesh);
   PUT_CI(hull_adj_start, s.hull_adj_start, s.nhullvert > 0 ? s.nhullvert + 1 : 0);
   PUT_CI(hull_adj, s.hull_adj, s.nhulladj);
+  {
+    // the direction-bin tables are per hull and live on the host while they are built: refuse a model whose tables
+    // would not fit rather than die in an allocation (the hand's 24 hulls: 0.23 GB)
+    const size_t per_hull = (size_t)BS_NSTART * (32 + 32 * BS_CAND_K);
+    if ((size_t)s.nmesh * per_hull > ((size_t)16 << 30))
+      return fail(BS_ERR_NOMEM, "bs_model_create: the collision tables of %d hulls (%zu bytes per hull: 6 x %d x %d direction bins, start record + %d "
+                  "support candidates each) exceed 16 GiB; compile with a smaller -DBS_SG", s.nmesh, per_hull, BS_SG, BS_SG, BS_CAND_K);
+  }
   // climb warm-start table: exhaustive support vertex for the centre direction of every bin
   std::vector<int32_t> hstart((size_t)(s.nmesh > 0 ? s.nmesh : 1) * BS_NSTART, 0);
   // support candidates: per bin the vertices that are the hull's support vertex for SOME direction of the bin (the
