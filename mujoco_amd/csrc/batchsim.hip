@@ -298,6 +298,13 @@ static void build_tp(bs_model* mdl, int variant) {
   for (int b = 1; b < nb; b++)
     if (jnt_of[b] >= 0 && depth[b] < mind) mind = depth[b];
   m->tp.fold_minlvl = mind + 1 < 2 ? 2 : mind + 1;
+  {
+    // the fold at fold_minlvl goes into one body (lvl_parent) that carries the shallowest dof, and that dof has no
+    // ancestor dof: the kernels need only two scalars of it (physics_tp.h, "palm")
+    const int L = m->tp.fold_minlvl, top = L < TP_MAXLVL ? m->tp.lvl_parent[L] : -1;
+    m->tp.palm_scalar = top > 0 && jnt_of[top] >= 0 && depth[top] == mind && L == mind + 1 && at(TPI_DD, top) == 1 ? 1 : 0;
+    if (getenv("BS_NO_PALM_SCALAR")) m->tp.palm_scalar = 0;
+  }
   m->tp.jump_rounds = 0;
   while ((1 << m->tp.jump_rounds) < maxdepth) m->tp.jump_rounds++;
   m->tp_ok = 1;

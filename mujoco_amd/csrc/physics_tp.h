@@ -107,6 +107,7 @@ struct TpModel {
   int maxdepth, maxdd, nroots;
   int jump_rounds;  // ceil(log2(maxdepth)): pointer-jumping rounds that reach the world from every body
   int fold_minlvl;  // leaves-to-root folds (crb, rne forces) stop here: no body above this depth carries a dof
+  int palm_scalar;  // 1: the fold at fold_minlvl goes into ONE body whose dof has no ancestor dof (a palm): only two scalars are needed of it
   // PGS sweep order (mj_solPGS visits the rows in efc order: equality, frictionloss, limits): owner lanes
   // of the equality rows in equality order; the other rows follow the dof order, which is the lane order
   const int* pgs_order;
@@ -1459,6 +1460,8 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
       TpRow Mr;
       {
         double crb[10];
+        double palm_m = 0, palm_b = 0;
+        bool palm_top = false;
 #pragma unroll
         for (int k = 0; k < 10; k++) crb[k] = cinert[k];
         for (int lvl = t.maxdepth; lvl >= (FULL ? 2 : t.fold_minlvl); lvl--) {
@@ -1468,6 +1471,38 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
             // environment's lanes (DPP, VALU rate) instead of one ds_bpermute round per child — the contact-free
             // kernels are bound by the CU's LDS pipe in this section (the contact kernels neither gain nor lose).
             const bool kid = isb && depth == lvl, top = l == t.lvl_parent[lvl];
+            if (!FULL && t.palm_scalar && lvl == t.fold_minlvl) {
+              // Round 3: the last fold of a hand goes into the palm, whose composite inertia and force are used for
+              // exactly two numbers — the palm dof's diagonal entry cdof . (I_c cdof) and its bias force cdof . f — and
+              // both are LINEAR in what is folded: every child projects its own composite on the palm's motion axis and
+              // two scalars are summed over the environment, where the fold summed sixteen values (a fifteenth of the
+              // contact-free kernel's instructions, and sixteen dependent reductions).  Summation order differs from the
+              // fold's by rounding; every instantiation shares this code.
+              const int top_sa = (base + t.lvl_parent[lvl]) * 4;
+              double cp[6], tb[6];
+#pragma unroll
+              for (int k = 0; k < 6; k++) cp[k] = bperm(cdof[k], top_sa);
+              // (spelled in fused multiply-adds of a fixed order: left to the compiler's contraction the two
+              // instantiations that are compared bit for bit — chain and generic — rounded these sums differently)
+              {
+                const double* I = crb;
+                const double* v = cp;
+                tb[0] = __builtin_fma(I[7], v[5], __builtin_fma(-I[8], v[4], __builtin_fma(I[4], v[2], __builtin_fma(I[3], v[1], I[0] * v[0]))));
+                tb[1] = __builtin_fma(-I[6], v[5], __builtin_fma(I[8], v[3], __builtin_fma(I[5], v[2], __builtin_fma(I[1], v[1], I[3] * v[0]))));
+                tb[2] = __builtin_fma(I[6], v[4], __builtin_fma(-I[7], v[3], __builtin_fma(I[2], v[2], __builtin_fma(I[5], v[1], I[4] * v[0]))));
+                tb[3] = __builtin_fma(I[9], v[3], __builtin_fma(-I[7], v[2], I[8] * v[1]));
+                tb[4] = __builtin_fma(I[9], v[4], __builtin_fma(-I[8], v[0], I[6] * v[2]));
+                tb[5] = __builtin_fma(I[9], v[5], __builtin_fma(-I[6], v[1], I[7] * v[0]));
+              }
+              double s1 = cp[0] * tb[0], s2 = cp[0] * f[0];
+#pragma unroll
+              for (int k = 1; k < 6; k++) { s1 = __builtin_fma(cp[k], tb[k], s1); s2 = __builtin_fma(cp[k], f[k], s2); }
+              const bool sel = kid || top;
+              palm_m = env_sum(sel ? s1 : 0.0);
+              palm_b = env_sum(sel ? s2 : 0.0);
+              palm_top = top;
+              continue;
+            }
 #pragma unroll
             for (int k = 0; k < 10; k++) { const double sk = env_sum(kid ? crb[k] : 0.0); if (top) crb[k] += sk; }
 #pragma unroll
@@ -1497,13 +1532,13 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
         double s = 0;
 #pragma unroll
         for (int k = 0; k < 6; k++) s += cdof[k] * f[k];
-        qfrc_bias = s;
+        qfrc_bias = palm_top ? palm_b : s;
         double buf[6];
         mul_inert_vec(buf, crb, cdof);
         double s0 = 0;
 #pragma unroll
         for (int k = 0; k < 6; k++) s0 += cdof[k] * buf[k];
-        Mr.r[0] = has_dof ? lk[TPK_ARMATURE] + s0 : 1.0;
+        Mr.r[0] = has_dof ? lk[TPK_ARMATURE] + (palm_top ? palm_m : s0) : 1.0;
         double cds[6], cdtop[6];
 #pragma unroll
         for (int k = 0; k < 6; k++) { cds[k] = cdof[k]; cdtop[k] = CHAIN ? bperm(cdof[k], c.top_sa) : 0.0; }

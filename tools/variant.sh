@@ -13,8 +13,8 @@ pids=()
 for o in "$@"; do
   case $o in
     batchsim|k_serial|k_narrow) src=$o.hip; def="" ;;
-    k_*) src=k_tp_kernels.hip; def="-DTPK_${o#k_}" ;;
-    w_*) src=k_tp_kernels.hip; def="-DTP_LPE=64 -DTPK_${o#w_}" ;;
+    k_*) src=k_tp_kernels.hip; def="-ffp-contract=on -DTPK_${o#k_}" ;;
+    w_*) src=k_tp_kernels.hip; def="-ffp-contract=on -DTP_LPE=64 -DTPK_${o#w_}" ;;
   esac
   /opt/rocm/bin/hipcc $BASE $def $FLAGS -c -o $OUT/$o.o $src &
   pids+=($!)
