@@ -2036,33 +2036,21 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
               if (lo == j1) y = y1;
               AB[lo] = tp_d2{a, b};
               tp_wave_sync();
-              // TPC_ROWB rows per round of broadcast reads, the next round's reads issued before this round's FMAs
-#ifndef TPC_ROWB
-#define TPC_ROWB 4
-#endif
+              // four rows per round of broadcast reads (six / eight / twelve rows, or the next round's reads issued before
+              // this round's FMAs, measured the same or slower: the column already holds 48 registers)
               {
-                tp_d2 cur[TPC_ROWB], nxt[TPC_ROWB];
+                tp_d2 cur[4];
 #pragma unroll
-                for (int q = 0; q < TPC_ROWB; q++)
+                for (int q = 0; q < 4; q++)
                   if (q < j0) cur[q] = AB[q];
 #pragma unroll
-                for (int i0 = 0; i0 < j0; i0 += TPC_ROWB) {
-#ifdef TPC_PREFETCH
+                for (int i0 = 0; i0 < j0; i0 += 4) {
 #pragma unroll
-                  for (int q = 0; q < TPC_ROWB; q++)
-                    if (i0 + TPC_ROWB + q < j0) nxt[q] = AB[i0 + TPC_ROWB + q];
-#endif
-#pragma unroll
-                  for (int q = 0; q < TPC_ROWB; q++)
+                  for (int q = 0; q < 4; q++)
                     if (i0 + q < j0) h[i0 + q] = (h[i0 + q] - cur[q].x * a) - cur[q].y * b;
-#ifdef TPC_PREFETCH
 #pragma unroll
-                  for (int q = 0; q < TPC_ROWB; q++) cur[q] = nxt[q];
-#else
-#pragma unroll
-                  for (int q = 0; q < TPC_ROWB; q++)
-                    if (i0 + TPC_ROWB + q < j0) cur[q] = AB[i0 + TPC_ROWB + q];
-#endif
+                  for (int q = 0; q < 4; q++)
+                    if (i0 + 4 + q < j0) cur[q] = AB[i0 + 4 + q];
                 }
               }
               tp_wave_sync();
