@@ -279,6 +279,22 @@ static void build_tp(bs_model* mdl, int variant) {
     if (s.njnt > 0) {
       for (int q = 0; q < 3; q++) { r[TPK_JPOS + q] = s.jnt_pos[3 * jj + q]; r[TPK_JAX + q] = s.jnt_axis[3 * jj + q]; }
       r[TPK_ARMATURE] = s.dof_armature[jj];
+      {  // closed-form joint-local pose constants (physics_tp.h, TPK_P1)
+        const Q4 bq = {r[TPK_BQUAT], r[TPK_BQUAT + 1], r[TPK_BQUAT + 2], r[TPK_BQUAT + 3]};
+        const M3 Rb = q2m(bq);
+        const V3 k = {r[TPK_JAX], r[TPK_JAX + 1], r[TPK_JAX + 2]}, jp = {r[TPK_JPOS], r[TPK_JPOS + 1], r[TPK_JPOS + 2]};
+        V3 p1, p2;
+        if (s.jnt_type[jj] == BS_JNT_SLIDE) { p1 = {0, 0, 0}; p2 = mrot(Rb, k); }
+        else {
+          const double kj = k.x * jp.x + k.y * jp.y + k.z * jp.z;
+          p1 = mrot(Rb, V3{jp.x - k.x * kj, jp.y - k.y * kj, jp.z - k.z * kj});
+          p2 = mrot(Rb, cross(k, jp));
+        }
+        const Q4 q1 = qmul(bq, Q4{0.0, k.x, k.y, k.z});
+        r[TPK_P1] = p1.x; r[TPK_P1 + 1] = p1.y; r[TPK_P1 + 2] = p1.z;
+        r[TPK_P2] = p2.x; r[TPK_P2 + 1] = p2.y; r[TPK_P2 + 2] = p2.z;
+        r[TPK_Q1] = q1.w; r[TPK_Q1 + 1] = q1.x; r[TPK_Q1 + 2] = q1.y; r[TPK_Q1 + 3] = q1.z;
+      }
       r[TPK_JMARGIN] = s.jnt_margin[jj]; r[TPK_JRANGE] = s.jnt_range[2 * jj]; r[TPK_JRANGE + 1] = s.jnt_range[2 * jj + 1];
       for (int q = 0; q < 5; q++) r[TPK_JSOLIMP + q] = s.jnt_solimp[5 * jj + q];
     }

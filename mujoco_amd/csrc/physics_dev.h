@@ -74,11 +74,11 @@ struct V3 { double x, y, z; };
 struct Q4 { double w, x, y, z; };
 struct M3 { double a[9]; };
 
-__device__ __forceinline__ Q4 qmul(const Q4& a, const Q4& b) {
+__host__ __device__ __forceinline__ Q4 qmul(const Q4& a, const Q4& b) {
   return {a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z, a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y,
           a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x, a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w};
 }
-__device__ __forceinline__ M3 q2m(const Q4& q) {
+__host__ __device__ __forceinline__ M3 q2m(const Q4& q) {
   double q00 = q.w * q.w, q01 = q.w * q.x, q02 = q.w * q.y, q03 = q.w * q.z;
   double q11 = q.x * q.x, q12 = q.x * q.y, q13 = q.x * q.z, q22 = q.y * q.y, q23 = q.y * q.z,
          q33 = q.z * q.z;

@@ -95,7 +95,10 @@ enum {
   TPK_D0 = 24,                          // + TPD_* field
   TPK_JMARGIN = TPK_D0 + TPD_TOTAL, TPK_JRANGE, TPK_JSOLIMP = TPK_JRANGE + 2,
   TPK_EQDATA = TPK_JSOLIMP + 5, TPK_EQSOLIMP = TPK_EQDATA + 5, TPK_EQQPOS0 = TPK_EQSOLIMP + 5,  // of the equality the lane owns; qpos0 of its other joint
-  TPK_N = (TPK_EQQPOS0 + 2) & ~1
+  // joint-local pose in closed form (host-built): hinge  lp = bpos + (1-cos)*P1 - sin*P2,  lq = cos(h)*bquat + sin(h)*Q1
+  // with P1 = R_b (jpos - k (k.jpos)), P2 = R_b (k x jpos), Q1 = bquat * (0, k);  slide  lp = bpos + dq*P2, P2 = R_b k
+  TPK_P1 = TPK_EQQPOS0 + 1, TPK_P2 = TPK_P1 + 3, TPK_Q1 = TPK_P2 + 3,
+  TPK_N = (TPK_Q1 + 5) & ~1
 };
 
 struct TpModel {
@@ -1031,12 +1034,12 @@ __device__ __forceinline__ void tp_collide_prep(const DevModel& m, const TpModel
   const int par_sa = pv >= 0 ? (base + pv) * 4 : self_sa;
   const int jnt = t.lane[TPI_JNT * TP_LPE + l];
   const bool has_dof = jnt >= 0, isb = l < m.nbody && l > 0;
-  const int b = l < m.nbody ? l : 0, j = has_dof ? jnt : 0;
+  const int j = has_dof ? jnt : 0;
   // (the state is loaded on every lane, row 0 where there is no dof, and selected afterwards: guarded loads were
   // emitted one behind the other, each with its own wait; the pose constants come from the lane's one record)
   const double qpos_l = AT(d.qpos, j), qvel_l = AT(d.qvel, j);
   const double* const lk = t.lane_k + l * TPK_N;
-  const V3 bpos = ld3(lk + TPK_BPOS), jpos = ld3(lk + TPK_JPOS), jax = ld3(lk + TPK_JAX);
+  const V3 bpos = ld3(lk + TPK_BPOS);
   const Q4 bquat = ld4(lk + TPK_BQUAT);
   const int jtype = m.jnt_type[j];
   const double qpos0 = m.qpos0[j];
@@ -1046,18 +1049,18 @@ __device__ __forceinline__ void tp_collide_prep(const DevModel& m, const TpModel
   const double dq = qpos - qpos0;
   Q4 lq = bquat;
   V3 lp = bpos;
-  if (has_dof) {
+  if (has_dof) {  // the closed form of tp_run's joint-local pose
+    const V3 p2 = ld3(lk + TPK_P2);
     if (jtype == BS_JNT_SLIDE) {
-      const V3 s = mrot(q2m(bquat), jax);
-      lp = {bpos.x + s.x * dq, bpos.y + s.y * dq, bpos.z + s.z * dq};
+      lp = {bpos.x + p2.x * dq, bpos.y + p2.y * dq, bpos.z + p2.z * dq};
     } else {
       double sn, cs;
       sincos(0.5 * dq, &sn, &cs);
-      const Q4 qj = {cs, jax.x * sn, jax.y * sn, jax.z * sn};
-      lq = qmul(bquat, qj);
-      const V3 rj = mrot(q2m(qj), jpos);
-      const V3 dl = mrot(q2m(bquat), V3{jpos.x - rj.x, jpos.y - rj.y, jpos.z - rj.z});
-      lp = {bpos.x + dl.x, bpos.y + dl.y, bpos.z + dl.z};
+      const V3 p1 = ld3(lk + TPK_P1);
+      const Q4 q1 = ld4(lk + TPK_Q1);
+      const double omc = 2.0 * (sn * sn), s1 = 2.0 * (sn * cs);
+      lq = {cs * bquat.w + sn * q1.w, cs * bquat.x + sn * q1.x, cs * bquat.y + sn * q1.y, cs * bquat.z + sn * q1.z};
+      lp = {(bpos.x + omc * p1.x) - s1 * p2.x, (bpos.y + omc * p1.y) - s1 * p2.y, (bpos.z + omc * p1.z) - s1 * p2.z};
     }
   }
   V3 pos;
@@ -1337,17 +1340,18 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
       Q4 lq = bquat;
       V3 lp = bpos;
       if (has_dof) {
+        // closed form of bquat * (cos h, k sin h) and bpos + R_b (jpos - R(k, dq) jpos), h = dq / 2 (TPK_P1 .. TPK_Q1)
+        const V3 p2 = ld3(lk + TPK_P2);
         if (jtype == BS_JNT_SLIDE) {
-          const V3 s = mrot(q2m(bquat), jax);
-          lp = {bpos.x + s.x * dq, bpos.y + s.y * dq, bpos.z + s.z * dq};
+          lp = {bpos.x + p2.x * dq, bpos.y + p2.y * dq, bpos.z + p2.z * dq};
         } else {
           const TpSinCos sc = tp_sincos(0.5 * dq);
           const double sn = sc.sn, cs = sc.cs;
-          const Q4 qj = {cs, jax.x * sn, jax.y * sn, jax.z * sn};
-          lq = qmul(bquat, qj);
-          const V3 rj = mrot(q2m(qj), jpos);
-          const V3 dl = mrot(q2m(bquat), V3{jpos.x - rj.x, jpos.y - rj.y, jpos.z - rj.z});
-          lp = {bpos.x + dl.x, bpos.y + dl.y, bpos.z + dl.z};
+          const V3 p1 = ld3(lk + TPK_P1);
+          const Q4 q1 = ld4(lk + TPK_Q1);
+          const double omc = 2.0 * (sn * sn), s1 = 2.0 * (sn * cs);  // 1 - cos dq, sin dq
+          lq = {cs * bquat.w + sn * q1.w, cs * bquat.x + sn * q1.x, cs * bquat.y + sn * q1.y, cs * bquat.z + sn * q1.z};
+          lp = {(bpos.x + omc * p1.x) - s1 * p2.x, (bpos.y + omc * p1.y) - s1 * p2.y, (bpos.z + omc * p1.z) - s1 * p2.z};
         }
       }
       TPC_T(19)
