@@ -275,6 +275,15 @@ static void build_tp(bs_model* mdl, int variant) {
     for (int q = 0; q < 3; q++) { r[TPK_BPOS + q] = s.body_pos[3 * b + q]; r[TPK_IPOS + q] = s.body_ipos[3 * b + q]; r[TPK_INERTIA + q] = s.body_inertia[3 * b + q]; }
     for (int q = 0; q < 4; q++) { r[TPK_BQUAT + q] = s.body_quat[4 * b + q]; r[TPK_IQUAT + q] = s.body_iquat[4 * b + q]; }
     for (int f = 0; f < TPD_TOTAL; f++) r[TPK_D0 + f] = dat(f, l);
+    {  // Ib = R_i diag(I) R_i^T
+      const M3 Ri = q2m(Q4{r[TPK_IQUAT], r[TPK_IQUAT + 1], r[TPK_IQUAT + 2], r[TPK_IQUAT + 3]});
+      const int ij[6][2] = {{0, 0}, {1, 1}, {2, 2}, {0, 1}, {0, 2}, {1, 2}};
+      for (int q = 0; q < 6; q++) {
+        double v = 0;
+        for (int k = 0; k < 3; k++) v += Ri.a[3 * ij[q][0] + k] * r[TPK_INERTIA + k] * Ri.a[3 * ij[q][1] + k];
+        r[TPK_IB + q] = v;
+      }
+    }
     const int jj = j >= 0 ? j : 0;
     if (s.njnt > 0) {
       for (int q = 0; q < 3; q++) { r[TPK_JPOS + q] = s.jnt_pos[3 * jj + q]; r[TPK_JAX + q] = s.jnt_axis[3 * jj + q]; }

@@ -98,7 +98,8 @@ enum {
   // joint-local pose in closed form (host-built): hinge  lp = bpos + (1-cos)*P1 - sin*P2,  lq = cos(h)*bquat + sin(h)*Q1
   // with P1 = R_b (jpos - k (k.jpos)), P2 = R_b (k x jpos), Q1 = bquat * (0, k);  slide  lp = bpos + dq*P2, P2 = R_b k
   TPK_P1 = TPK_EQQPOS0 + 1, TPK_P2 = TPK_P1 + 3, TPK_Q1 = TPK_P2 + 3,
-  TPK_N = (TPK_Q1 + 5) & ~1
+  TPK_IB = TPK_Q1 + 4,                    // body inertia about its centre of mass in the BODY frame: 00 11 22 01 02 12
+  TPK_N = (TPK_IB + 7) & ~1
 };
 
 struct TpModel {
@@ -259,30 +260,35 @@ __device__ __forceinline__ void tp_chain_sum(double* v, int par_sa, int rounds, 
     jp = jn;
   }
 }
-// world pose of every body from the poses relative to the parent (lp, lq); quaternions are
-// normalised after every composition, as mj_kinematics normalises every body's
+// world pose of every body from the poses relative to the parent (lp, lq).  mj_kinematics normalises every body's
+// quaternion after its composition; products of unit quaternions stay unit to rounding, so ONE normalisation after the
+// last round gives the same result to a few ulp (3 x ~20 instructions less), and the parent's rotation is applied in
+// quaternion form (v + 2 w (u x v) + 2 u x (u x v): 18 instructions, 31 through the matrix)
+__device__ __forceinline__ V3 tp_qrot(const Q4& q, const V3& v) {
+  const V3 c = {q.y * v.z - q.z * v.y, q.z * v.x - q.x * v.z, q.x * v.y - q.y * v.x};
+  const V3 t = {c.x + c.x, c.y + c.y, c.z + c.z};
+  return {(v.x + q.w * t.x) + q.y * t.z - q.z * t.y, (v.y + q.w * t.y) + q.z * t.x - q.x * t.z,
+          (v.z + q.w * t.z) + q.x * t.y - q.y * t.x};
+}
 __device__ __forceinline__ void tp_chain_pose(V3& pos, Q4& quat, const V3& lp, const Q4& lq, int par_sa, int world_sa,
                                               int rounds, bool isb) {
-  auto unit = [](Q4& q) {
-    const double inv = tp_rsqrt(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
-    q.w *= inv; q.x *= inv; q.y *= inv; q.z *= inv;
-  };
   pos = {0, 0, 0};
   quat = {1, 0, 0, 0};
-  if (isb) { pos = lp; quat = lq; unit(quat); }
+  if (isb) { pos = lp; quat = lq; }
   int jp = par_sa;
   for (int r = 0; r < rounds; r++) {
     const V3 pp = {bperm(pos.x, jp), bperm(pos.y, jp), bperm(pos.z, jp)};
     const Q4 pq = {bperm(quat.w, jp), bperm(quat.x, jp), bperm(quat.y, jp), bperm(quat.z, jp)};
     const int jn = __builtin_amdgcn_ds_bpermute(jp, jp);
     if (isb && jp != world_sa) {
-      const V3 tt = mrot(q2m(pq), pos);
+      const V3 tt = tp_qrot(pq, pos);
       pos = {pp.x + tt.x, pp.y + tt.y, pp.z + tt.z};
       quat = qmul(pq, quat);
-      unit(quat);
     }
     jp = jn;
   }
+  const double inv = tp_rsqrt(quat.w * quat.w + quat.x * quat.x + quat.y * quat.y + quat.z * quat.z);
+  quat.w *= inv; quat.x *= inv; quat.y *= inv; quat.z *= inv;
 }
 __device__ __forceinline__ constexpr int pair_idx(int a, int b) {  // 1 <= a <= b <= TP_MAXD-1
   return (a - 1) * (TP_MAXD - 1) - (a - 1) * (a - 2) / 2 + (b - a);
@@ -1394,14 +1400,19 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
       }
       double cinert[10], cdof[6];
       {
-        const M3 R = q2m(qmul(quat, ld4(lk + TPK_IQUAT)));
-        const double* I = lk + TPK_INERTIA;
+        // xmat Ib xmat^T with Ib = R_i diag(I) R_i^T built on the host (TPK_IB: 00 11 22 01 02 12): 45 instructions where
+        // composing the inertial frame's quaternion, its matrix and the diagonal product took 65
+        const M3& R = xmat;
+        const double* I = lk + TPK_IB;
         const double off[3] = {xipos.x - com.x, xipos.y - com.y, xipos.z - com.z};
         double tt[9];
 #pragma unroll
-        for (int rr = 0; rr < 3; rr++)
-#pragma unroll
-          for (int k = 0; k < 3; k++) tt[3 * rr + k] = R.a[3 * rr + k] * I[k];
+        for (int rr = 0; rr < 3; rr++) {
+          const double a = R.a[3 * rr], bb = R.a[3 * rr + 1], cc = R.a[3 * rr + 2];
+          tt[3 * rr] = a * I[0] + bb * I[3] + cc * I[4];
+          tt[3 * rr + 1] = a * I[3] + bb * I[1] + cc * I[5];
+          tt[3 * rr + 2] = a * I[4] + bb * I[5] + cc * I[2];
+        }
         cinert[0] = tt[0] * R.a[0] + tt[1] * R.a[1] + tt[2] * R.a[2];
         cinert[1] = tt[3] * R.a[3] + tt[4] * R.a[4] + tt[5] * R.a[5];
         cinert[2] = tt[6] * R.a[6] + tt[7] * R.a[7] + tt[8] * R.a[8];
