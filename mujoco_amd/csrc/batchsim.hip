@@ -5,6 +5,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -275,6 +276,14 @@ static void build_tp(bs_model* mdl, int variant) {
     for (int q = 0; q < 3; q++) { r[TPK_BPOS + q] = s.body_pos[3 * b + q]; r[TPK_IPOS + q] = s.body_ipos[3 * b + q]; r[TPK_INERTIA + q] = s.body_inertia[3 * b + q]; }
     for (int q = 0; q < 4; q++) { r[TPK_BQUAT + q] = s.body_quat[4 * b + q]; r[TPK_IQUAT + q] = s.body_iquat[4 * b + q]; }
     for (int f = 0; f < TPD_TOTAL; f++) r[TPK_D0 + f] = dat(f, l);
+    // the closed forms below and the kernels' single normalisation per chain pose take unit quaternions (mjModel's are;
+    // arrays handed straight to bs_model_create may be a few digits short): rescaled here when they are not
+    auto unit = [](double* v, int n) {
+      double n2 = 0;
+      for (int q = 0; q < n; q++) n2 += v[q] * v[q];
+      if (n2 > 0 && std::fabs(n2 - 1.0) > 1e-15) { const double sc = 1.0 / std::sqrt(n2); for (int q = 0; q < n; q++) v[q] *= sc; }
+    };
+    unit(r + TPK_BQUAT, 4); unit(r + TPK_IQUAT, 4);
     {  // Ib = R_i diag(I) R_i^T
       const M3 Ri = q2m(Q4{r[TPK_IQUAT], r[TPK_IQUAT + 1], r[TPK_IQUAT + 2], r[TPK_IQUAT + 3]});
       const int ij[6][2] = {{0, 0}, {1, 1}, {2, 2}, {0, 1}, {0, 2}, {1, 2}};
@@ -287,6 +296,7 @@ static void build_tp(bs_model* mdl, int variant) {
     const int jj = j >= 0 ? j : 0;
     if (s.njnt > 0) {
       for (int q = 0; q < 3; q++) { r[TPK_JPOS + q] = s.jnt_pos[3 * jj + q]; r[TPK_JAX + q] = s.jnt_axis[3 * jj + q]; }
+      unit(r + TPK_JAX, 3);
       r[TPK_ARMATURE] = s.dof_armature[jj];
       {  // closed-form joint-local pose constants (physics_tp.h, TPK_P1)
         const Q4 bq = {r[TPK_BQUAT], r[TPK_BQUAT + 1], r[TPK_BQUAT + 2], r[TPK_BQUAT + 3]};

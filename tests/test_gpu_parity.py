@@ -1112,3 +1112,30 @@ def test_vec_env_fused_period_matches_torch_path(hand_model):
                 assert torch.equal(getattr(sims[0].data, f), getattr(sims[1].data, f)), (period, f)
         for s in sims:
             s.close()
+
+
+def test_non_unit_model_quaternions_are_rescaled_on_the_host(hand_model):
+    """The tree-parallel kernels' closed-form joint pose and single normalisation per chain pose assume unit body / inertial
+    quaternions and joint axes (mjModel's are: MuJoCo's compiler normalises them).  Arrays a few digits short of unit — as a
+    caller of bs_model_create might pass — are rescaled when the lane record is built: same poses and mass matrix."""
+    import torch
+    from mujoco_amd import BatchSim, workload
+    m = workload.contact_free(hand_model)
+    m2 = m.copy()
+    m2.body_quat = m.body_quat * (1.0 + 1e-4 * np.arange(m.nbody))[:, None]
+    m2.body_iquat = m.body_iquat * 0.999
+    m2.jnt_axis = m.jnt_axis * 1.0005
+    E = 64
+    q, v = workload.config2_state(m, E, seed=5)
+    c = workload.config2_ctrl(m, E, seed=5)
+    out = []
+    for mm in (m, m2):
+        sim = BatchSim(mm, n_envs=E)
+        assert sim.kernel_path()[0]
+        sim.data.qpos.copy_(torch.as_tensor(q)); sim.data.qvel.copy_(torch.as_tensor(v)); sim.data.ctrl.copy_(torch.as_tensor(c))
+        sim.forward(); sim.sync()
+        out.append({f: getattr(sim.data, f).cpu().numpy().copy() for f in ("xpos", "xquat", "qM", "qacc")})
+        sim.close()
+    for f in ("xpos", "xquat", "qM", "qacc"):
+        a, b = out
+        assert np.abs(a[f] - b[f]).max() <= 1e-12 * max(1.0, np.abs(a[f]).max()), f
