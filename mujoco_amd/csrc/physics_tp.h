@@ -1385,6 +1385,16 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
         xipos = {pos.x + ip.x, pos.y + ip.y, pos.z + ip.z};
       }
       V3 com = {0, 0, 0};
+      if constexpr (!FULL) {
+        // Reference point of the tree's spatial quantities.  mj_comPos takes the subtree centre of mass of the body's
+        // root; the mass matrix, the bias forces and the contact Jacobians do not depend on the point (only cinert /
+        // cdof / cvel do, and those are outputs of the full-dump kernels alone, which keep the centre of mass): the
+        // step kernels take the root body's own inertial position — one fetch, where the centre of mass is three
+        // environment-wide sums in front of everything that follows.  Results differ by rounding.
+        const int ra = isb ? (base + root) * 4 : self_sa;
+        const double rx = bperm(xipos.x, ra), ry = bperm(xipos.y, ra), rz = bperm(xipos.z, ra);
+        if (isb) com = {rx, ry, rz};
+      } else
       for (int r = 0; r < t.nroots; r++) {
         const int rb = t.roots[r];
         const bool mine = isb && root == rb;
