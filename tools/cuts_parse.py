@@ -9,7 +9,8 @@ d = sys.argv[1]
 order = json.load(open("gpurun_out/cuts_order.json"))
 kern = "k_tp_chain" if order["free"] else "k_tpc_chain"
 per_step = 1 if order["free"] else 3   # launches of the kernel per step (three ranges with contacts)
-f = glob.glob(f"{d}/**/*counter_collection.csv", recursive=True)[0]
+import os
+f = max(glob.glob(f"{d}/**/*counter_collection.csv", recursive=True), key=os.path.getmtime)   # the newest run in the directory
 disp = collections.OrderedDict()
 for r in csv.DictReader(open(f)):
     if not r["Kernel_Name"].startswith(kern):
