@@ -1139,3 +1139,77 @@ def test_non_unit_model_quaternions_are_rescaled_on_the_host(hand_model):
     for f in ("xpos", "xquat", "qM", "qacc"):
         a, b = out
         assert np.abs(a[f] - b[f]).max() <= 1e-12 * max(1.0, np.abs(a[f]).max()), f
+
+
+_SLIDE_HINGE_XML = """<mujoco><compiler angle="radian"/><option timestep="0.002"/>
+<default><joint damping="0.2" armature="0.01" frictionloss="0.002" margin="0.01"/><geom density="800" contype="0" conaffinity="0"/></default>
+<worldbody>
+ <body name="base" pos="0 0 0.5" quat="0.9 0.1 0.3 0.2">
+  <joint name="s0" type="slide" axis="1 2 0.5" pos="0.01 0.02 0.03" range="-0.2 0.2" limited="true"/>
+  <geom type="box" size="0.05 0.03 0.02" pos="0.01 0 0.02" quat="0.8 0.2 0.1 0.5"/>
+  <body name="l1" pos="0.1 0 0.05" quat="0.7 0.5 0.1 0.4">
+   <joint name="h1" type="hinge" axis="0.3 1 0.2" pos="0.02 -0.01 0.03" range="-1 1" limited="true"/>
+   <geom type="capsule" size="0.02 0.06" pos="0 0.02 0.05" quat="0.9 0.3 0.2 0.1"/>
+   <body name="l2" pos="0 0.05 0.12" quat="0.6 0.2 0.7 0.1">
+    <joint name="s2" type="slide" axis="0 0.4 1" pos="0.01 0.01 0" range="-0.1 0.1" limited="true"/>
+    <geom type="box" size="0.02 0.04 0.03" pos="0.01 0.01 0.02" quat="0.5 0.5 0.1 0.7"/>
+    <body name="l3" pos="0.03 0 0.08" quat="0.2 0.9 0.3 0.1">
+     <joint name="h3" type="hinge" axis="1 0 0.1" pos="0 0.01 -0.02" range="-1.2 0.8" limited="true"/>
+     <geom type="capsule" size="0.015 0.05" pos="0.01 0 0.04" quat="0.7 0.1 0.6 0.3"/>
+    </body>
+   </body>
+   <body name="m2" pos="0.04 -0.05 0.1" quat="0.3 0.1 0.2 0.9">
+    <joint name="h4" type="hinge" axis="0 1 1" pos="0.01 0 0.01" range="-0.7 0.7" limited="true"/>
+    <geom type="box" size="0.02 0.02 0.05" pos="0 0.01 0.05" quat="0.9 0.1 0.4 0.1"/>
+   </body>
+  </body>
+ </body>
+</worldbody>
+<actuator><position joint="s0" kp="50"/><position joint="h1" kp="5"/><position joint="s2" kp="30"/><position joint="h3" kp="2"/></actuator>
+</mujoco>"""
+
+
+@pytest.mark.parametrize("env", [{}, {"BS_KERNEL": "wide"}])
+def test_slide_and_hinge_tree_with_rotated_frames_matches_the_oracle(env, monkeypatch):
+    """Slide and hinge joints mixed in one branching tree, every body / joint / inertial frame rotated and offset: the
+    closed-form joint-local pose (TPK_P1 / P2 / Q1), the body-frame inertia tensor (TPK_IB) and the root-body reference
+    point of the step kernels against the oracle's mj_kinematics / mj_comPos / mj_crb arithmetic."""
+    import torch
+    import mujoco_amd
+    from mujoco_amd import BatchSim
+    from oracle import OracleSim
+    m = mujoco_amd.load_model_from_xml(_SLIDE_HINGE_XML)
+    assert m.nv == 5 and m.nbody == 6
+    E = 70
+    rng = np.random.default_rng(11)
+    lo, hi = m.jnt_range[:, 0], m.jnt_range[:, 1]
+    q = lo + (hi - lo) * rng.uniform(-0.1, 1.1, size=(E, m.nq))   # some beyond their limits
+    v = rng.normal(size=(E, m.nv)) * 0.5
+    c = rng.uniform(-0.5, 0.5, size=(E, m.nu))
+    for k, val in env.items():
+        monkeypatch.setenv(k, val)
+    sim = BatchSim(m, n_envs=E)
+    for k in env:
+        monkeypatch.delenv(k)
+    fast, path = sim.kernel_path()
+    assert fast and ("_w" in path) == bool(env), path
+    sim.data.qpos.copy_(torch.as_tensor(q)); sim.data.qvel.copy_(torch.as_tensor(v)); sim.data.ctrl.copy_(torch.as_tensor(c))
+    sim.forward(); sim.sync()
+    xpos, xquat, qM, qacc, bias = (getattr(sim.data, f).cpu().numpy() for f in ("xpos", "xquat", "qM", "qacc", "qfrc_bias"))
+    for e in range(0, E, 3):
+        s = OracleSim(m)
+        s.qpos[:] = q[e]; s.qvel[:] = v[e]; s.ctrl[:] = c[e]
+        s.forward()
+        assert np.abs(xpos[e] - s.xpos).max() <= 1e-12 and np.abs(xquat[e] - s.xquat).max() <= 1e-12, e
+        assert np.abs(qM[e] - s.qM).max() <= 1e-12 * np.abs(s.qM).max(), e
+        assert np.abs(bias[e] - s.qfrc_bias).max() <= 1e-12 * max(1.0, np.abs(s.qfrc_bias).max()), e
+        assert np.abs(qacc[e] - s.qacc).max() <= 1e-8 * max(1.0, np.abs(s.qacc).max()), e
+    sim.step(50); sim.sync()   # the step kernels (root-body reference point)
+    qg, vg = sim.data.qpos.cpu().numpy(), sim.data.qvel.cpu().numpy()
+    assert int((sim.data.warning != 0).sum()) == 0
+    for e in range(0, E, 7):
+        s = OracleSim(m)
+        s.qpos[:] = q[e]; s.qvel[:] = v[e]; s.ctrl[:] = c[e]
+        s.step(50)
+        assert np.abs(qg[e] - s.qpos).max() < 1e-9 and np.abs(vg[e] - s.qvel).max() < 1e-7, (e, np.abs(qg[e] - s.qpos).max(), np.abs(vg[e] - s.qvel).max())
+    sim.close()
