@@ -1463,10 +1463,10 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
         for (int k = 0; k < 6; k++) cvel[k] = isb ? cdof[k] * qvel : 0.0;
         tp_chain_sum<6>(cvel, par_sa, t.jump_rounds, isb);
         {
-          double pv[6], cdd[6];
-#pragma unroll
-          for (int k = 0; k < 6; k++) pv[k] = bperm(cvel[k], par_sa);
-          cross_motion(cdd, pv, cdof);
+          // (the body's own cvel stands in for its parent's: they differ by cdof * qvel, and the motion cross product of
+          // cdof with itself is zero — one cross-lane round trip less in the chain between the two sums)
+          double cdd[6];
+          cross_motion(cdd, cvel, cdof);
 #pragma unroll
           for (int k = 0; k < 6; k++) acc[k] = isb ? cdd[k] * qvel : 0.0;
         }
