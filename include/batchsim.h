@@ -39,7 +39,9 @@ typedef enum bs_status {
 /* Flattened model (the build's mjModel): arrays produced by the host-side MJCF compiler
  * (mujoco_amd/mjcf.py), copied to the device once by bs_model_create.  Field names follow
  * mjModel.  Replaces the result of mujoco-py load_model_from_xml (reference
- * src/Mujoco_XML.py:341). */
+ * src/Mujoco_XML.py:341).  body_quat, body_iquat and jnt_axis are unit vectors in an mjModel
+ * (MuJoCo's compiler normalises them); the tree-parallel kernels' per-lane tables rescale ones
+ * that are not, the generic kernels use the arrays as given. */
 typedef struct bs_model_desc {
   int32_t nbody, njnt, nv, nu, ngeom, neq, nmesh, nM, npair, nhullvert, nhulladj;
   int32_t integrator; /* 0 Euler, 1 RK4 */
