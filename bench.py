@@ -507,7 +507,10 @@ def main():
                 except Exception as ex:  # the pool is informational; the single-thread figure is the contract
                     out["cpu_baseline_allcores"] = {"error": repr(ex)}
             if not args.no_extra_blocks:
-                out["config1_4096"] = config1_block(model_path, 4096, local_rank, seed, args.steps, args.warmup, not args.no_cpu_baseline)
+                # whole control periods: the first steps after a ctrl resample take twice the Newton iterations of the
+                # settled ones, so a region shorter than a period (the driver's --steps 20) would time the transient only
+                c1_steps = -(-max(args.steps, 2 * CTRL_PERIOD) // CTRL_PERIOD) * CTRL_PERIOD
+                out["config1_4096"] = config1_block(model_path, 4096, local_rank, seed, c1_steps, max(args.warmup, CTRL_PERIOD), not args.no_cpu_baseline)
                 b2, _ = contacts_block(model_path, 65536, local_rank, seed, min(args.steps, 200), min(args.warmup, 50), 1, None, 0,
                                        "BASELINE.json configs[2]: " + CONTACT_LABEL + ", 65536 envs, no collective")
                 if "cpu_baseline" in out:  # the same model and workload per environment as the headline's
