@@ -333,6 +333,10 @@ static void build_tp(bs_model* mdl, int variant) {
   for (int b = 1; b < nb; b++)
     if (jnt_of[b] >= 0 && depth[b] < mind) mind = depth[b];
   m->tp.fold_minlvl = mind + 1 < 2 ? 2 : mind + 1;
+  m->tp.first_dof = 0;
+  for (int b = 1; b < nb; b++)
+    if (jnt_of[b] >= 0) { m->tp.first_dof = b; break; }
+  if (getenv("BS_NO_FIRST_DOF")) m->tp.first_dof = 0;
   {
     // the fold at fold_minlvl goes into one body (lvl_parent) that carries the shallowest dof, and that dof has no
     // ancestor dof: the kernels need only two scalars of it (physics_tp.h, "palm")

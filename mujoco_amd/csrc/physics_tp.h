@@ -111,6 +111,7 @@ struct TpModel {
   int maxdepth, maxdd, nroots;
   int jump_rounds;  // ceil(log2(maxdepth)): pointer-jumping rounds that reach the world from every body
   int fold_minlvl;  // leaves-to-root folds (crb, rne forces) stop here: no body above this depth carries a dof
+  int first_dof;    // lowest lane with a dof: the rows below it are identity rows of the Newton Hessian (k_tpc skips their panels and unknowns)
   int palm_scalar;  // 1: the fold at fold_minlvl goes into ONE body whose dof has no ancestor dof (a palm): only two scalars are needed of it
   // PGS sweep order (mj_solPGS visits the rows in efc order: equality, frictionloss, limits): owner lanes
   // of the equality rows in equality order; the other rows follow the dof order, which is the lane order
@@ -2039,7 +2040,7 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
 #pragma unroll
             for (int j1 = TPC_NREG - 1; j1 >= 1; j1 -= 2) {
               const int j0 = j1 - 1;
-              if (j0 >= n) continue;  // wave-uniform
+              if (j0 >= n || j1 < t.first_dof) continue;  // wave-uniform; rows without a dof (identity rows, zero right-hand sides) are left as they are
               const int sa1 = base4 + 4 * j1, sa0 = base4 + 4 * j0;
               double d1 = bperm(h[j1], sa1);
               const double x10 = bperm(h[j1], sa0), d0r = bperm(h[j0], sa0);
@@ -2092,7 +2093,7 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
 #endif
           Gs[l] = greg;
           tp_wave_sync();
-          for (int j1 = n - 1; j1 >= 0; j1 -= 2) {
+          for (int j1 = n - 1; j1 >= t.first_dof; j1 -= 2) {  // (panels of rows without a dof: identity rows, nothing to do)
             const int t1 = j1 * (j1 + 1) / 2, j0 = j1 - 1;
             const tp_lds_d H1 = Hs + t1;
             double d1 = H1[j1];
@@ -2163,7 +2164,7 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
             const tp_lds_d Lrow = l < n ? Hrow : Hs;  // lanes beyond the bodies read row 0 (their result is unused)
             const double invl = l < n ? Hrow[l] : 0.0;
 #pragma unroll 4
-            for (int k = 0; k < n; k++) {
+            for (int k = t.first_dof; k < n; k++) {  // the unknowns of the identity rows below the first dof are zero
               const double xl = (y - acc) * invl;
               const double xk = bperm(xl, (base + k) * 4);
               if (l == k) xres = xl;
