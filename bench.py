@@ -12,7 +12,7 @@ augmentation), 131 072 envs per GPU, Euler + Newton, fp64, ctrl resampled every 
 reward all-gathered over RCCL once per control period, overlapped with the next steps (weak scaling, no traffic
 inside a step).  The line carries `ranks_joined` (an all-reduce of 1) and every rank's device name.
 N = 1 adds, in the same line, `cpu_baseline` (the oracle on the same workload) and the blocks
-    "config1_4096":    configs[1] — joint-space only (contacts disabled), 4096 lockstep envs (k_tp_chain), with its
+    "config1_4096":    configs[1] — joint-space only (contacts disabled), 4096 lockstep envs (k_tp_chain4), with its
                        own `roofline` and `cpu_baseline`;
     "contacts_65536":  configs[2] — the headline's model at 65 536 envs without the collective, with `roofline`.
 
@@ -332,7 +332,7 @@ def config1_block(model_path, E, local_rank, seed, steps, warmup, with_cpu):
     m = w.measure(steps, warmup)
     stats = w.state_stats()
     path = w.sim.kernel_path()[1]
-    kern = "k_tp_chain" if "k_tp_chain" in path else "k_tp"
+    kern = "k_tp_chain4" if "k_tp_chain4" in path else "k_tp_chain" if "k_tp_chain" in path else "k_tp"
     traffic, src = pmc_traffic("config1_pmc_per_launch" if E == 4096 else "none", ("k_tp",))
     blk = {"value": E * steps / m["wall"], "unit": "env-steps/s", "ms_per_step": m["wall"] * 1e3 / steps,
            "steps": steps, "reps": len(m["walls"]), "wall_s_all_reps": m["walls"],
@@ -548,7 +548,7 @@ def main():
         wall = m["wall"]
         path = w.sim.kernel_path()[1]
         chain = "k_tp_chain" in path or "k_tpc_chain" in path
-        kern = ("k_tp_chain" if chain else "k_tp") if args.solver == "newton" else ("k_tp_cg" if args.solver == "cg" else "k_tp_pgs")
+        kern = ("k_tp_chain4" if "chain4" in path else "k_tp_chain" if chain else "k_tp") if args.solver == "newton" else ("k_tp_cg" if args.solver == "cg" else "k_tp_pgs")
         hw = (None, None)
         if args.contacts:
             traffic, src = pmc_traffic("contacts_pmc_per_step" if E == 65536 and not args.hull_verts else "none",

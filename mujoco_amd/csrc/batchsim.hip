@@ -333,6 +333,18 @@ static void build_tp(bs_model* mdl, int variant) {
   for (int b = 1; b < nb; b++)
     if (jnt_of[b] >= 0 && depth[b] < mind) mind = depth[b];
   m->tp.fold_minlvl = mind + 1 < 2 ? 2 : mind + 1;
+  {
+    // hands: every body after the first dof body ("palm") in aligned groups of four lanes, each a chain off the palm
+    int top = -1;
+    for (int b = 1; b < nb; b++)
+      if (jnt_of[b] >= 0) { top = b; break; }
+    bool ok = m->tp.chain && top > 0 && (top + 1) % 4 == 0 && nb <= 32 && LPE == 32 && !getenv("BS_NO_QUAD");
+    for (int b = top + 1; ok && b < nb; b++) {
+      const int q = (b - top - 1) % 4;
+      if (s.body_parentid[b] != (q == 0 ? top : b - 1)) ok = false;
+    }
+    m->tp.quad_top = ok ? top : -1;
+  }
   m->tp.first_dof = 0;
   for (int b = 1; b < nb; b++)
     if (jnt_of[b] >= 0) { m->tp.first_dof = b; break; }
@@ -1151,7 +1163,7 @@ static void launch_step(bs_sim* s, int n_steps) {
     const bool rk = s->dm.integrator == 1;
     auto* launch = s->dm.solver == 0 ? (rk ? bs_launch_tp_rk4_pgs : bs_launch_tp_pgs)
                    : s->dm.solver == 1 ? (rk ? bs_launch_tp_rk4_cg : bs_launch_tp_cg)
-                                       : (rk ? bs_launch_tp_rk4 : (s->tp.chain ? bs_launch_tp_chain : bs_launch_tp));
+                                       : (rk ? bs_launch_tp_rk4 : (s->tp.chain ? (s->tp.quad_top >= 0 ? bs_launch_tp_chain4 : bs_launch_tp_chain) : bs_launch_tp));
     if (s->wide)
       launch = s->dm.solver == 0 ? (rk ? bs_launch_tp_rk4_pgs_w : bs_launch_tp_pgs_w)
                : s->dm.solver == 1 ? (rk ? bs_launch_tp_rk4_cg_w : bs_launch_tp_cg_w) : (rk ? bs_launch_tp_rk4_w : bs_launch_tp_w);
@@ -1487,7 +1499,7 @@ extern "C" int bs_sim_kernel_path(const bs_sim* s, char* buf, int cap) {
     if (s->contacts)
       fastname = std::string("tree-parallel (k_tp_col") + w + ", k_c_narrow_list, k_tpc" + (chain ? "_chain" : sol) + w + ")";
     else
-      fastname = std::string("tree-parallel (k_tp") + (chain && s->dm.integrator == 0 ? "_chain" : (std::string(s->dm.integrator == 1 ? "_rk4" : "") + sol).c_str()) + w + ")";
+      fastname = std::string("tree-parallel (k_tp") + (chain && s->dm.integrator == 0 ? (s->tp.quad_top >= 0 ? "_chain4" : "_chain") : (std::string(s->dm.integrator == 1 ? "_rk4" : "") + sol).c_str()) + w + ")";
   }
   snprintf(buf, (size_t)cap, "%s%s", tp ? fastname.c_str()
                                        : (s->contacts ? "serial (k_c_pos, k_c_broad, k_c_narrow_flat, k_c_dyn): " : "serial (k_step): "),

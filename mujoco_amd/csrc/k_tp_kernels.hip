@@ -20,8 +20,8 @@
 #define TP_OCC 2
 #endif
 
-#define TP_KERNEL(name, CONTACTS_, FULL_, RK4_, CG_, PGS_, PARK_, MINV_) TP_KERNEL_C(name, CONTACTS_, FULL_, RK4_, CG_, PGS_, PARK_, MINV_, false)
-#define TP_KERNEL_C(name, CONTACTS_, FULL_, RK4_, CG_, PGS_, PARK_, MINV_, CHAIN_)                                   \
+#define TP_KERNEL(name, CONTACTS_, FULL_, RK4_, CG_, PGS_, PARK_, MINV_) TP_KERNEL_C(name, CONTACTS_, FULL_, RK4_, CG_, PGS_, PARK_, MINV_, false, false)
+#define TP_KERNEL_C(name, CONTACTS_, FULL_, RK4_, CG_, PGS_, PARK_, MINV_, CHAIN_, QUAD_)                                   \
   __global__ __launch_bounds__(64, TP_OCC) void KN(name)(DevModel m, TpModel t, DevData d, int nsteps, int mode, int dump) { \
     __shared__ int tbl[TPL_TOTAL * 64];                                                                               \
     __shared__ double park[PARK_ ? (TP_MAXD + 1) * 64 : 1];                                                           \
@@ -29,7 +29,7 @@
     const TpShared sh = {tbl, nullptr, nullptr, nullptr, PARK_ ? park : nullptr, MINV_ ? minv : nullptr};             \
     ColModel cm;                                                                                                      \
     ColData cd;                                                                                                       \
-    tp_run<CONTACTS_, FULL_, RK4_, CG_, PGS_, CHAIN_>(m, t, d, nsteps, mode, dump, sh, cm, cd);                       \
+    tp_run<CONTACTS_, FULL_, RK4_, CG_, PGS_, CHAIN_, QUAD_>(m, t, d, nsteps, mode, dump, sh, cm, cd);                \
   }                                                                                                                   \
   void LN(name)(BS_TP_ARGS) { hipLaunchKernelGGL(KN(name), g, dim3(64), lds, st, m, t, d, nsteps, mode, dump); }
 
@@ -62,15 +62,15 @@
 // contacts: candidates from k_tp_col + the narrowphase kernel, one step per launch.  Dynamic LDS:
 // packed Hessians for nbody rows (2 envs), then contact slots, then the U staging rows
 #define TPC_KERNEL(name, CG_, PGS_) TPC_KERNEL_F(name, false, CG_, PGS_)
-#define TPC_KERNEL_F(name, FULL_, CG_, PGS_) TPC_KERNEL_FC(name, FULL_, CG_, PGS_, false)
-#define TPC_KERNEL_FC(name, FULL_, CG_, PGS_, CHAIN_)                                                                  \
+#define TPC_KERNEL_F(name, FULL_, CG_, PGS_) TPC_KERNEL_FC(name, FULL_, CG_, PGS_, false, false)
+#define TPC_KERNEL_FC(name, FULL_, CG_, PGS_, CHAIN_, QUAD_)                                                                  \
   __global__ __launch_bounds__(64, TPC_OCC) void KN(name)(DevModel m, TpModel t, DevData d, ColModel cm, ColData cd,  \
                                                           int mode, int dump) {                                      \
     __shared__ int tbl[TPL_TOTAL * 64];                                                                               \
     extern __shared__ double tpc_dyn[];                                                                               \
     const int ntri = m.nbody * (m.nbody + 1) / 2;                                                                     \
     const TpShared sh = {tbl, tpc_dyn, tpc_dyn + TP_ENVS * ntri, tpc_dyn + TP_ENVS * ntri + 64 * TPC_SLOT, nullptr, nullptr}; \
-    tp_run<true, FULL_, false, CG_, PGS_, CHAIN_>(m, t, d, 1, mode, dump, sh, cm, cd);                                \
+    tp_run<true, FULL_, false, CG_, PGS_, CHAIN_, QUAD_>(m, t, d, 1, mode, dump, sh, cm, cd);                         \
   }                                                                                                                   \
   void LN(name)(BS_TPC_ARGS) { hipLaunchKernelGGL(KN(name), g, dim3(64), lds, st, m, t, d, cm, cd, mode, dump); }
 
@@ -79,7 +79,11 @@ TP_KERNEL(tp, false, false, false, false, false, true, false)
 #elif defined(TPK_tp_chain)
 // Euler + Newton, contact-free, for models whose dofs below the first branching form single-child chains on
 // consecutive lanes (TpModel::chain): the sweeps' packets of those levels move by DPP shifts
-TP_KERNEL_C(tp_chain, false, false, false, false, false, true, false, true)
+TP_KERNEL_C(tp_chain, false, false, false, false, false, true, false, true, false)
+#elif defined(TPK_tp_chain4)
+// ... whose chains are aligned groups of four lanes off one body (TpModel::quad_top, the exported hands): the chain sums
+// by DPP quad permutes as well
+TP_KERNEL_C(tp_chain4, false, false, false, false, false, true, false, true, true)
 #elif defined(TPK_tp_cg)
 TP_KERNEL_D(tp_cg, false, false, false, true, false, true, false)
 #elif defined(TPK_tp_pgs)
@@ -122,7 +126,9 @@ void LN(tp_col)(dim3 g, size_t lds, hipStream_t st, const DevModel& m, const TpM
 #elif defined(TPK_tpc)
 TPC_KERNEL(tpc, false, false)
 #elif defined(TPK_tpc_chain)
-TPC_KERNEL_FC(tpc_chain, false, false, false, true)  // Newton with contacts, chain models (see k_tp_chain)
+// Newton with contacts, chain models (see k_tp_chain).  No chain4 instantiation: the quad chain sums were measured in
+// this kernel too and cost more than they saved (51.1 against 51.5 M env-steps/s; scratch 144 -> 192 B per lane)
+TPC_KERNEL_FC(tpc_chain, false, false, false, true, false)
 #elif defined(TPK_tpc_cg)
 TPC_KERNEL_D(tpc_cg, true, false)
 #elif defined(TPK_tpc_full)

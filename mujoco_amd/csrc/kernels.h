@@ -56,6 +56,7 @@ void bs_np_profile_dump();
 #define BS_TP_ARGS dim3 g, size_t lds, hipStream_t st, const DevModel &m, const TpModel &t, const DevData &d, int nsteps, int mode, int dump
 void bs_launch_tp(BS_TP_ARGS);          // Newton, Euler
 void bs_launch_tp_chain(BS_TP_ARGS);          // Newton, Euler
+void bs_launch_tp_chain4(BS_TP_ARGS);         // ... hand-shaped models (TpModel::quad_top)
 void bs_launch_tp_cg(BS_TP_ARGS);       // CG, Euler
 void bs_launch_tp_pgs(BS_TP_ARGS);      // PGS, Euler (lds: M^-1 of the two environments)
 void bs_launch_tp_rk4(BS_TP_ARGS);

@@ -111,6 +111,7 @@ struct TpModel {
   int maxdepth, maxdd, nroots;
   int jump_rounds;  // ceil(log2(maxdepth)): pointer-jumping rounds that reach the world from every body
   int fold_minlvl;  // leaves-to-root folds (crb, rne forces) stop here: no body above this depth carries a dof
+  int quad_top;     // >= 0: lane of the one body every chain hangs off, (quad_top + 1) % 4 == 0, every later body sits in an aligned group of four lanes that is a chain off that body (tp_chain_sum_quad); -1 otherwise
   int first_dof;    // lowest lane with a dof: the rows below it are identity rows of the Newton Hessian (k_tpc skips their panels and unknowns)
   int palm_scalar;  // 1: the fold at fold_minlvl goes into ONE body whose dof has no ancestor dof (a palm): only two scalars are needed of it
   // PGS sweep order (mj_solPGS visits the rows in efc order: equality, frictionloss, limits): owner lanes
@@ -260,6 +261,28 @@ __device__ __forceinline__ void tp_chain_sum(double* v, int par_sa, int rounds, 
       for (int k = 0; k < N; k++) v[k] += w[k];
     jp = jn;
   }
+}
+// The same sums for a hand (TpModel::quad_top: every body after the palm sits in an aligned group of four lanes that is a
+// chain off the palm, and nothing above the palm carries a dof, so every term above it is zero): the parent of a chain's
+// first body is the palm, whose value never changes (it only ever receives zeros) and is fetched ONCE; inside a group the
+// parent is one lane down and the grandparent two — DPP quad permutes at VALU rate, no LDS-pipe instruction.  The three
+// rounds add exactly what the three pointer-jumping rounds add, in their order (masks are 0 / 1 factors: x + 1 * y and
+// x + 0 * y are x + y and x), so the kernel that uses it (k_tp_chain4 = tp_run<..., CHAIN, QUAD>) stays bit-identical to the generic one.
+template <int N>
+__device__ __forceinline__ void tp_chain_sum_quad(double* v, int top_sa, int l, int top, int nbody) {
+  const int ql = l & 3;
+  const bool in = l > top && l < nbody;
+  const double m1 = in && ql != 0 ? 1.0 : 0.0, p1 = in && ql == 0 ? 1.0 : 0.0;
+  const double m2 = in && ql >= 2 ? 1.0 : 0.0, p2 = in && ql == 1 ? 1.0 : 0.0, p3 = in && ql == 3 ? 1.0 : 0.0;
+  double pal[N];
+#pragma unroll
+  for (int k = 0; k < N; k++) pal[k] = bperm(v[k], top_sa);
+#pragma unroll
+  for (int k = 0; k < N; k++) v[k] = __builtin_fma(p1, pal[k], __builtin_fma(m1, dpp_mov<0x90>(v[k]), v[k]));  // quad_perm [0,0,1,2]: the parent
+#pragma unroll
+  for (int k = 0; k < N; k++) v[k] = __builtin_fma(p2, pal[k], __builtin_fma(m2, dpp_mov<0x44>(v[k]), v[k]));  // quad_perm [0,1,0,1]: two up, its sum so far
+#pragma unroll
+  for (int k = 0; k < N; k++) v[k] = __builtin_fma(p3, pal[k], v[k]);                                           // four up: the palm
 }
 // world pose of every body from the poses relative to the parent (lp, lq).  mj_kinematics normalises every body's
 // quaternion after its composition; products of unit quaternions stay unit to rounding, so ONE normalisation after the
@@ -1230,12 +1253,13 @@ __device__ __forceinline__ void tp_collide_prep(const DevModel& m, const TpModel
 // generalized forces of the last forward pass, 2: every intermediate the parity tests read.
 // CON: one step per launch with the contact candidates of k_c_broad / k_c_narrow (physics_collide.h):
 // contact assembly, pyramid rows owned by lanes, dense Hessian per environment in LDS.
+// QUAD (with CHAIN): the chain sums of hand-shaped models by DPP quad permutes (tp_chain_sum_quad).
 // CG: mj_solCG instead of mj_solNewton (same primal loop, line search and stopping rule; the search
 // direction is Polak-Ribiere in the M^-1 inner product, physics_dev.h::cg_gradient) — no Hessian.
 // PGS: mj_solPGS (dual, projected Gauss-Seidel): M^-1 is formed column by
 // column in LDS, the sweep visits the rows in efc order, the owner lane of a row computes its new
 // force and broadcasts the change, every dof lane adds change * (M^-1 J^T)_i to its acceleration.
-template <bool CON, bool FULL, bool RK4, bool CG = false, bool PGS = false, bool CHAIN = false>
+template <bool CON, bool FULL, bool RK4, bool CG = false, bool PGS = false, bool CHAIN = false, bool QUAD = false>
 __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, const DevData& d, int nsteps,
                                        int mode, int dump, TpShared sh, const ColModel& cm, const ColData& cd) {
   int* tbl = sh.tbl;
@@ -1462,7 +1486,8 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
         double acc[6];
 #pragma unroll
         for (int k = 0; k < 6; k++) cvel[k] = isb ? cdof[k] * qvel : 0.0;
-        tp_chain_sum<6>(cvel, par_sa, t.jump_rounds, isb);
+        if constexpr (CHAIN && QUAD) tp_chain_sum_quad<6>(cvel, (base + t.quad_top) * 4, l, t.quad_top, m.nbody);
+        else tp_chain_sum<6>(cvel, par_sa, t.jump_rounds, isb);
         {
           // (the body's own cvel stands in for its parent's: they differ by cdof * qvel, and the motion cross product of
           // cdof with itself is zero — one cross-lane round trip less in the chain between the two sums)
@@ -1471,7 +1496,8 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
 #pragma unroll
           for (int k = 0; k < 6; k++) acc[k] = isb ? cdd[k] * qvel : 0.0;
         }
-        tp_chain_sum<6>(acc, par_sa, t.jump_rounds, isb);
+        if constexpr (CHAIN && QUAD) tp_chain_sum_quad<6>(acc, (base + t.quad_top) * 4, l, t.quad_top, m.nbody);
+        else tp_chain_sum<6>(acc, par_sa, t.jump_rounds, isb);
         if (isb && !(m.disableflags & BS_DSBL_GRAVITY)) {
           acc[3] -= m.gravity[0]; acc[4] -= m.gravity[1]; acc[5] -= m.gravity[2];
         }
@@ -1662,7 +1688,8 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
           double cv[6];
 #pragma unroll
           for (int k = 0; k < 6; k++) cv[k] = isb ? cdof[k] * x : 0.0;
-          tp_chain_sum<6>(cv, par_sa, t.jump_rounds, isb);
+          if constexpr (CHAIN && QUAD) tp_chain_sum_quad<6>(cv, (base + t.quad_top) * 4, l, t.quad_top, m.nbody);
+        else tp_chain_sum<6>(cv, par_sa, t.jump_rounds, isb);
           double v1[6], v2[6];
 #pragma unroll
           for (int k = 0; k < 6; k++) { v1[k] = bperm(cv[k], b1_sa); v2[k] = bperm(cv[k], b2_sa); }
@@ -1684,7 +1711,8 @@ __device__ __forceinline__ void tp_run(const DevModel& m, const TpModel& t, cons
           double cv[12];
 #pragma unroll
           for (int k = 0; k < 6; k++) { cv[k] = isb ? cdof[k] * x0 : 0.0; cv[6 + k] = isb ? cdof[k] * x1 : 0.0; }
-          tp_chain_sum<12>(cv, par_sa, t.jump_rounds, isb);
+          if constexpr (CHAIN && QUAD) tp_chain_sum_quad<12>(cv, (base + t.quad_top) * 4, l, t.quad_top, m.nbody);
+        else tp_chain_sum<12>(cv, par_sa, t.jump_rounds, isb);
 #pragma unroll
           for (int h2 = 0; h2 < 2; h2++) {
             double v1[6], v2[6];

@@ -23,9 +23,9 @@ def agg(d):
 
 
 def fam(name):
-    """k_tp_chain / k_tpc_chain are the instantiations of k_tp / k_tpc this model runs (DPP shifts on the dof chains):
+    """k_tp_chain(4) / k_tpc_chain(4) are the instantiations of k_tp / k_tpc this model runs (DPP shifts on the dof chains):
     the summary keeps the family names its readers (bench.py) use; the kernel-stats CSVs keep the real ones."""
-    return name[:-6] if name.endswith("_chain") else name
+    return name[:-7] if name.endswith("_chain4") else name[:-6] if name.endswith("_chain") else name
 
 
 def stats(d, dst):

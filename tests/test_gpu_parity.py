@@ -450,30 +450,39 @@ def test_two_stream_split_is_bitwise_neutral(hand_model, integrator, monkeypatch
             assert np.array_equal(a, b)
 
 
-def test_chain_kernel_is_bitwise_neutral(hand_model, monkeypatch):
-    """k_tp_chain (DPP shifts instead of ds_bpermute for the sweeps' packets on the single-child levels of
-    the dof tree; chosen when TpModel::chain holds, as for the hand) moves the same values between the same
-    lanes as k_tp: not a bit of the trajectory may differ.  BS_NO_CHAIN=1 selects the generic kernel."""
+@pytest.mark.parametrize("contacts", [False, True])
+def test_chain_kernel_is_bitwise_neutral(hand_model, monkeypatch, contacts):
+    """k_tp_chain / k_tpc_chain (DPP shifts instead of ds_bpermute for the sweeps' packets on the single-child levels of
+    the dof tree; chosen when TpModel::chain holds) and k_tp_chain4 (the chain sums by DPP quad permutes as
+    well; chosen for hand-shaped models without contacts, TpModel::quad_top) move the same values between the same lanes as k_tp / k_tpc:
+    not a bit of the trajectory may differ.  BS_NO_QUAD=1 selects the chain kernels, BS_NO_CHAIN=1 the generic ones."""
     import torch
     from mujoco_amd import BatchSim, workload
-    m = workload.contact_free(hand_model)
+    m = workload.with_ground_plane(hand_model, z=-0.05) if contacts else workload.contact_free(hand_model)
     E = 130
     q, v = workload.config2_state(m, E, seed=77)
     c = workload.config2_ctrl(m, E, seed=77)
     res = {}
-    for mode in ("chain", "generic"):
-        if mode == "generic":
-            monkeypatch.setenv("BS_NO_CHAIN", "1")
-        sim = BatchSim(m.copy(), n_envs=E)  # a fresh native model per mode: the flag is read when the model is built
-        assert ("k_tp_chain" in sim.kernel_path()[1]) == (mode == "chain")
+    # (the contact kernel has no chain4 instantiation: with contacts the default IS k_tpc_chain)
+    for mode, var in ((("chain", None),) if contacts else (("chain4", None), ("chain", "BS_NO_QUAD"))) + (("generic", "BS_NO_CHAIN"),):
+        if var:
+            monkeypatch.setenv(var, "1")
+        sim = BatchSim(m.copy(), n_envs=E)  # a fresh native model per mode: the flags are read when the model is built
+        if var:
+            monkeypatch.delenv(var)
+        path = sim.kernel_path()[1]
+        stem = "k_tpc" if contacts else "k_tp"
+        assert ((stem + "_chain4") in path) == (mode == "chain4") and ((stem + "_chain") in path) == (mode != "generic"), (mode, path)
         sim.data.qpos.copy_(torch.as_tensor(q)); sim.data.qvel.copy_(torch.as_tensor(v)); sim.data.ctrl.copy_(torch.as_tensor(c))
-        sim.step(60); sim.sync()
+        sim.step(20 if contacts else 60); sim.sync()
         res[mode] = [getattr(sim.data, k).cpu().numpy().copy() for k in ("qpos", "qvel", "qacc", "solver_iter", "xpos")]
+        if contacts:
+            res[mode].append(sim.data.ncon.cpu().numpy().copy())
         del sim
-    monkeypatch.delenv("BS_NO_CHAIN")
-    assert np.abs(res["chain"][1]).max() > 1e-3
-    for a, b in zip(res["chain"], res["generic"]):
-        assert np.array_equal(a, b)
+    assert np.abs(res["chain"][1]).max() > 1e-3 and (not contacts or res["chain"][5].sum() > 100)
+    for mode in res:
+        for a, b in zip(res[mode], res["generic"]):
+            assert np.array_equal(a, b), mode
 
 
 def test_work_stealing_narrowphase(hand_model, monkeypatch):

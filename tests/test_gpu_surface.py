@@ -310,7 +310,7 @@ def test_solver_and_integrator_kwargs(hand_model):
     assert sim.kernel_path() == (True, "tree-parallel (k_tp_col, k_c_narrow_list, k_tpc_pgs)")
     sim.close()
     sim = BatchSim(free, n_envs=E, device_ids=[0])
-    assert sim.device_id == 0 and sim.kernel_path()[1] == "tree-parallel (k_tp_chain)"
+    assert sim.device_id == 0 and sim.kernel_path()[1] == "tree-parallel (k_tp_chain4)"
     sim.close()
     for bad in (dict(solver="sor"), dict(integrator="implicit"), dict(solver=5), dict(device_ids=[0, 0])):
         with pytest.raises(ValueError):
